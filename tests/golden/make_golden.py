@@ -1,0 +1,207 @@
+"""Generate the golden vectors from the REAL reference (run in the build container only).
+
+    python tests/golden/make_golden.py
+
+Imports /root/reference/src/SPART (tools/_ref_import.py), runs the reference's own functions on
+the parameter sets below and stores inputs + outputs as .npz next to this script.  The
+fixtures are data only; nothing of the reference's source is stored.  The GPU box has no
+/root/reference: tests there read the committed .npz files.
+
+Files
+  prospect.npz   leaf (n,9) + refl/tran/kChlrel (n,2001)   PROSPECT_5D (prospect_5d.py:117)
+  bsm.npz        soil (n,6) + refl/refl_dry (n,2001)       BSM (bsm.py:17)
+  sailh.npz      canopy (n,4), angles (n,3), lidf (n,13) + rso/rdo/rsd/rdd (n,2162)
+                 with the reference's default leaf/soil fixtures (tests/conftest.py:48-59)
+  smac.npz       per sensor: angles, atm + the 9 AtmosphericOptics fields (smac.py:14)
+  e2e.npz        full SPART(...).run() rows: defaults x 9 sensors, README/MODIS, PRO/S2B,
+                 256 rows of the config-4 LHS (S2A), 64 rows config-5 LHS (S2B), 32 LHS rows MODIS/L7/S3A
+"""
+import io
+import itertools
+import os
+import sys
+from contextlib import redirect_stdout
+from multiprocessing import Pool
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.normpath(os.path.join(HERE, "..", ".."))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from _ref_import import import_reference  # noqa: E402
+
+SPART = import_reference()
+sys.path.insert(0, os.path.join(ROOT, "spart-python_amd", "spart_amd"))
+import workloads  # noqa: E402  (plain module import: does not pull in the package / HIP lib)
+
+from SPART.bsm import BSM, SoilParameters  # noqa: E402
+from SPART.prospect_5d import PROSPECT_5D, LeafBiology  # noqa: E402
+from SPART.sailh import SAILH, Angles, CanopyStructure  # noqa: E402
+from SPART.smac import SMAC, AtmosphericProperties  # noqa: E402
+
+SENSORS = ["TerraAqua-MODIS", "LANDSAT4-TM", "LANDSAT5-TM", "LANDSAT7-ETM", "LANDSAT8-OLI",
+           "Sentinel2A-MSI", "Sentinel2B-MSI", "Sentinel3A-OLCI", "Sentinel3B-OLCI"]
+
+
+def sample_rows(n_total, n=10):
+    """Row positions pandas' DataFrame.sample(n, random_state=42) draws (tests/conftest.py:28-30)."""
+    import pandas as pd
+    return list(pd.DataFrame(index=range(n_total)).sample(n, random_state=42).index)
+
+
+def prospect_grid():
+    """build_PROSPECT_tests.py:38-50; the builder prepends each new row, so file row i is combination n-1-i."""
+    Cab = np.arange(10, 85, 10); Cca = np.arange(10, 35, 10); Cw = np.arange(0.02, 0.12, 0.04)
+    Cdm = np.arange(0.005, 0.025, 0.01); Cs = np.arange(0, 1.5, 0.5); Cant = np.arange(10, 35, 10)
+    N = np.arange(1.0, 3.5, 0.5)
+    g = list(itertools.product(Cab, Cdm, Cw, Cs, Cca, Cant, N))
+    return g[::-1]
+
+
+def sailh_grid():
+    """build_SAILH_tests.py:87-101."""
+    LAI = np.arange(1, 8, 3); a = np.arange(-1, 1, 0.4); b = np.arange(-1, 1, 0.4); q = np.arange(0.01, 0.2, 0.05)
+    s = np.arange(0, 75, 30); o = np.arange(0, 75, 30); r = np.arange(0, 180, 80)
+    g = list(itertools.product(LAI, a, b, q, s, o, r))
+    return g[::-1]
+
+
+def gen_prospect():
+    op = SPART.load_optical_parameters()
+    g = prospect_grid()
+    rows = [g[i] for i in sample_rows(len(g))] + [g[0], g[-1]]
+    leaf = [list(map(float, r)) + [0.0, 0.0] for r in rows]
+    # extra: defaults, README (Cdm=10 -> NaNs at 400-410nm), PRO cases, zero-absorption-ish, N=1
+    leaf += [[40, 0.01, 0.02, 0, 10, 10, 1.5, 0, 0], [40, 10, 0.02, 0.01, 0, 10, 1.5, 0, 0],
+             [40, 0.01, 0.02, 0, 10, 10, 1.5, 0.001, 0.009], [30, 0.0, 0.015, 0.1, 8, 2, 1.8, 0.002, 0.004],
+             [0, 0, 0, 0, 0, 0, 1.5, 0, 0], [5, 0.001, 0.001, 0, 1, 0, 1.0, 0, 0],
+             [80, 0.02, 0.05, 0.5, 20, 10, 3.0, 0, 0], [10, 0.002, 0.005, 0, 2, 0, 1.0, 0, 0]]
+    leaf = np.array(leaf, dtype=np.float64)
+    out = {k: [] for k in ("refl", "tran", "kChlrel")}
+    for r in leaf:
+        with redirect_stdout(io.StringIO()):
+            lo = PROSPECT_5D(LeafBiology(*r[:7], PROT=r[7], CBC=r[8]), op)
+        out["refl"].append(lo.refl[:, 0]); out["tran"].append(lo.tran[:, 0]); out["kChlrel"].append(lo.kChlrel[:, 0])
+    np.savez_compressed(os.path.join(HERE, "prospect.npz"), leaf=leaf, **{k: np.array(v) for k, v in out.items()})
+    print("prospect", leaf.shape)
+
+
+def gen_bsm():
+    op = SPART.load_optical_parameters()
+    soil = np.array([[0.5, 0, 100, 20, 25, 0.015], [0.5, 0, 100, 15, 25, 0.015], [0.5, 0, 100, 5, 25, 0.015],
+                     [0.5, 0, 100, 3, 25, 0.015], [0.9, 30, 120, 55, 25, 0.015], [0.3, -30, 80, 5.0001, 25, 0.015],
+                     [0.7, 10, 90, 40, 30, 0.02], [0.6, -12.5, 111, 27.5, 20, 0.01], [0.45, 20, 95, 80, 25, 0.015],
+                     [0.8, 0, 100, 10, 55, 0.005]], dtype=np.float64)
+    refl, dry = [], []
+    for r in soil:
+        so = BSM(SoilParameters(*r), op)
+        if isinstance(so, np.ndarray):   # (never: BSM returns SoilOptics also for mu<=0)
+            raise RuntimeError
+        refl.append(so.refl[:, 0]); dry.append(so.refl_dry[:, 0])
+    np.savez_compressed(os.path.join(HERE, "bsm.npz"), soil=soil, refl=np.array(refl), refl_dry=np.array(dry))
+    print("bsm", soil.shape)
+
+
+def default_optics():
+    op = SPART.load_optical_parameters()
+    lb = LeafBiology(40, 0.01, 0.02, 0, 10, 10, 1.5)
+    lo = SPART.set_leaf_refl_trans_assumptions(PROSPECT_5D(lb, op), lb, SPART.SpectralBands())
+    so = SPART.set_soil_refl_trans_assumptions(BSM(SoilParameters(0.5, 0, 100, 20, 25, 0.015), op), SPART.SpectralBands())
+    return lo, so
+
+
+def gen_sailh():
+    lo, so = default_optics()
+    g = sailh_grid()
+    rows = [g[i] for i in sample_rows(len(g))] + [g[0], g[-1]]
+    rows = [list(map(float, r)) for r in rows]
+    # extra: defaults, hot spot exactly (dso == 0) at nadir and off-nadir, small q, small LAI, psi folding
+    rows += [[3, -0.35, -0.15, 0.05, 40, 0, 0], [3, -0.35, -0.15, 0.05, 0, 0, 0], [4, 0.2, -0.1, 0.05, 30, 30, 0],
+             [2, -0.35, -0.15, 0.01, 60, 30, 160], [0.1, 0.1, 0.2, 0.2, 10, 25, 90], [7, -0.5, 0.3, 0.1, 55, 5, 270],
+             [5, 0.5, -0.3, 0.03, 20, 20, 365], [1.5, 0.0, 0.0, 0.15, 45, 15, 180]]
+    rows = np.array(rows, dtype=np.float64)
+    out = {k: [] for k in ("rso", "rdo", "rsd", "rdd", "lidf")}
+    for r in rows:
+        cs = CanopyStructure(*r[:4])
+        rad = SAILH(so, lo, cs, Angles(*r[4:7]))
+        for k in ("rso", "rdo", "rsd", "rdd"):
+            out[k].append(getattr(rad, k)[:, 0])
+        out["lidf"].append(cs.lidf[:, 0])
+    np.savez_compressed(os.path.join(HERE, "sailh.npz"), canopy=rows[:, :4], angles=rows[:, 4:7],
+                        leaf_refl=lo.refl[:, 0], leaf_tran=lo.tran[:, 0], soil_refl=so.refl[:, 0],
+                        **{k: np.array(v) for k, v in out.items()})
+    print("sailh", rows.shape)
+
+
+SMAC_FIELDS = ["Ta_s", "Ta_o", "Tg", "Ra_dd", "Ra_so", "Ta_ss", "Ta_sd", "Ta_oo", "Ta_do"]
+
+
+def gen_smac():
+    rng = np.random.default_rng(7)
+    out = {}
+    for s in ["Sentinel2A-MSI", "Sentinel2B-MSI", "TerraAqua-MODIS", "LANDSAT7-ETM", "LANDSAT8-OLI", "Sentinel3A-OLCI"]:
+        si = SPART.load_sensor_info(s)
+        ang = np.column_stack([rng.uniform(0, 60, 12), rng.uniform(0, 30, 12), rng.uniform(0, 180, 12)])
+        atm = np.column_stack([rng.uniform(0.05, 0.5, 12), rng.uniform(0.25, 0.45, 12), rng.uniform(0.5, 4, 12),
+                               rng.uniform(950, 1030, 12)])
+        ang[0] = [40, 0, 0]; atm[0] = [0.325, 0.35, 1.41, 1013.25]
+        ang[1] = [40, 0, 0]; atm[1] = [0.3246, 0.3480, 1.4116, 1013.25]
+        ang[2] = [30, 10, 180]; ang[3] = [0, 0, 0]
+        res = {f: [] for f in SMAC_FIELDS}
+        for a, t in zip(ang, atm):
+            ao = SMAC(Angles(*a), AtmosphericProperties(t[0], t[1], t[2], Pa=t[3]), si["SMAC_coef"])
+            nb = si["wl_smac"].shape[0]
+            for f in SMAC_FIELDS:
+                res[f].append(np.broadcast_to(np.asarray(getattr(ao, f), dtype=np.float64), (1, nb))[0].copy())
+        out[f"{s}/angles"] = ang; out[f"{s}/atm"] = atm
+        for f in SMAC_FIELDS:
+            out[f"{s}/{f}"] = np.array(res[f])
+    np.savez_compressed(os.path.join(HERE, "smac.npz"), **out)
+    print("smac done")
+
+
+def run_row(args):
+    row, sensor = args
+    leaf, soil, can, ang, atm, doy = row[0:9], row[9:15], row[15:19], row[19:22], row[22:26], row[26]
+    with redirect_stdout(io.StringIO()):
+        sp = SPART.SPART(SoilParameters(*soil), LeafBiology(*leaf[:7], PROT=leaf[7], CBC=leaf[8]),
+                         CanopyStructure(*can), AtmosphericProperties(atm[0], atm[1], atm[2], Pa=atm[3]),
+                         Angles(*ang), sensor, doy if doy != int(doy) else int(doy))
+        df = sp.run(debug=True)
+    probes = [0, 150, 400, 1000, 1600, 2000, 2100]   # 400, 550, 800, 1400, 2000, 2400 nm, first thermal
+    extra = np.concatenate([sp.leafopt.refl[probes, 0], sp.leafopt.tran[probes, 0], sp.soilopt.refl[probes, 0],
+                            sp.canopyopt.rso[probes, 0], sp.canopyopt.rdo[probes, 0],
+                            sp.canopyopt.rsd[probes, 0], sp.canopyopt.rdd[probes, 0]])
+    return (df["R_TOC"].to_numpy(), df["R_TOA"].to_numpy(), df["L_TOA"].to_numpy(), df["rsoil"].to_numpy(),
+            np.asarray(sp._La, dtype=np.float64), extra)
+
+
+def gen_e2e():
+    out = {}
+    groups = []
+    d = workloads.default_row()
+    for s in SENSORS:
+        groups.append((f"defaults/{s}", s, d))
+    readme = workloads.default_row(Cab=40, Cdm=10, Cw=0.02, Cs=0.01, Cca=0, Cant=10, N=1.5, SMp=15,
+                                   aot550=0.3246, uo3=0.3480, uh2o=1.4116, Pa=1013.25)
+    groups.append(("readme/TerraAqua-MODIS", "TerraAqua-MODIS", readme))
+    groups.append(("pro/Sentinel2B-MSI", "Sentinel2B-MSI", workloads.default_row(PROT=0.001, CBC=0.009)))
+    groups.append(("lhs_full/Sentinel2A-MSI", "Sentinel2A-MSI", workloads.lhs_params(1_000_000, "full")[:256]))
+    groups.append(("lhs_pro/Sentinel2B-MSI", "Sentinel2B-MSI", workloads.lhs_params(1_000_000, "pro")[:64]))
+    small = workloads.lhs_params(32, "full", seed=11)
+    for s in ["TerraAqua-MODIS", "LANDSAT7-ETM", "Sentinel3A-OLCI", "LANDSAT8-OLI"]:
+        groups.append((f"lhs_small/{s}", s, small))
+    with Pool(8) as pool:
+        for name, sensor, P in groups:
+            res = pool.map(run_row, [(r, sensor) for r in P], chunksize=4)
+            out[f"{name}/P"] = P
+            for j, k in enumerate(["R_TOC", "R_TOA", "L_TOA", "rsoil", "La", "probes"]):
+                out[f"{name}/{k}"] = np.array([r[j] for r in res])
+            print(name, P.shape, flush=True)
+    np.savez_compressed(os.path.join(HERE, "e2e.npz"), **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["prospect", "bsm", "sailh", "smac", "e2e"]
+    for w in which:
+        globals()["gen_" + w]()
