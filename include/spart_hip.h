@@ -1,0 +1,139 @@
+/* libspart_hip.so -- C ABI of the MI355X-native batched SPART evaluator.
+ *
+ * The reference (wirrell/SPART-python) has no FFI layer: its hot path is the five plain
+ * Python callables
+ *     BSM(soilpar, optical_params)                  src/SPART/bsm.py:17
+ *     PROSPECT_5D(leafbio, optical_params)          src/SPART/prospect_5d.py:117
+ *     SAILH(soil, leafopt, canopy, angles)          src/SPART/sailh.py:14
+ *     SMAC(angles, atm, coefs)                      src/SPART/smac.py:14
+ *     SPART(...).run()                              src/SPART/SPART.py:162
+ * Each entry point below replaces the arithmetic of one of them for a BATCH of B samples;
+ * INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every array pointer is DEVICE memory owned by the caller (e.g. a torch tensor's
+ *     data_ptr()); the library allocates only its context and never frees caller memory;
+ *   - per-sample inputs are structure-of-arrays, float64, length B (sample-level geometry is
+ *     always computed in float64);
+ *   - spectra and result columns are row-major (B, nbands), band-contiguous, in `dtype`;
+ *   - `stream` is a hipStream_t (NULL = default stream); calls are asynchronous on it;
+ *   - return value 0 = ok, <0 = error (spart_last_error gives the text).  Numerical trouble
+ *     propagates as NaN/inf exactly like the reference (no clamping).
+ */
+#ifndef SPART_HIP_H
+#define SPART_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPART_NWL 2001      /* 400..2400 nm            (SPART.py:303)      */
+#define SPART_NWLS 2162     /* + 161 thermal bands      (SPART.py:307-310)  */
+#define SPART_NLINCL 13     /* leaf inclination classes (sailh.py:346)      */
+#define SPART_NPARAM 27     /* parameter columns of spart_run_batch         */
+#define SPART_NCOEF 48      /* SMAC coefficient rows    (smac.py:44-92)     */
+
+#define SPART_F32 0
+#define SPART_F64 1
+
+#define SPART_OK 0
+#define SPART_ERR_INVALID (-1)    /* bad argument                          */
+#define SPART_ERR_HIP (-2)        /* HIP runtime error                     */
+#define SPART_ERR_WORKSPACE (-3)  /* workspace missing or too small        */
+#define SPART_ERR_NOSENSOR (-4)   /* context was created without a sensor  */
+
+typedef struct spart_ctx spart_ctx;
+
+/* Static tables, HOST pointers, float64; copied to the device by spart_ctx_create.
+ * Spectral tables are the arrays of the reference's optical_params.pkl / ET_irradiance.pkl
+ * (SPART.py:399-416), length 2001; the sensor block is sensor_information/<sensor>.pkl
+ * (SPART.py:419-424): keys wl_smac, SMAC_coef, wl_srf_smac, p_srf_smac.  nb = 0 builds a
+ * context without sensor (leaf / soil / canopy entry points only). */
+typedef struct spart_tables {
+  const double *nr, *Kab, *Kca, *Kdm, *Kw, *Ks, *Kant, *cbc, *prot; /* prospect_5d.py:158-167 */
+  const double *GSV;                                                /* (2001,3) row-major, bsm.py:45 */
+  const double *nw;                                                 /* bsm.py:55 */
+  const double *Ea;                                                 /* SPART.py:181 */
+  int32_t nb;                                                       /* sensor bands */
+  const double *wl_smac;                                            /* (nb,) band centres, nm */
+  const double *coef;                                               /* (48, nb) row-major, rows in smac.py:44-92 order
+                                                                       (ah2o nh2o ao3 no3 ao2 no2 po2 aco2 nco2 pco2 ach4 nch4 pch4
+                                                                       ano2 nno2 pno2 aco nco pco a0s a1s a2s a3s a0T a1T a2T a3T taur
+                                                                       a0taup a1taup wo gc a0P a1P a2P a3P a4P Rest1..4 Resr1..3 Resa1..4) */
+  int32_t nsrf;                                                     /* SRF samples per band */
+  const double *wl_srf;                                             /* (nsrf, nb) row-major, NaN padded */
+  const double *p_srf;                                              /* (nsrf, nb) row-major */
+} spart_tables;
+
+/* Optional full-spectrum outputs of spart_run_batch (the reference object's soilopt /
+ * leafopt / canopyopt attributes, SPART.py:66-81).  NULL members are skipped. */
+typedef struct spart_materialize {
+  void *leaf_refl, *leaf_tran; /* (B,2162) thermal-padded, SPART.py:445-470 */
+  void *leaf_kchl;             /* (B,2001) kChlrel, prospect_5d.py:197-198   */
+  void *soil_refl;             /* (B,2162) wet soil, padded SPART.py:427-442 */
+  void *soil_refl_dry;         /* (B,2001)                                    */
+  void *rso, *rdo, *rsd, *rdd; /* (B,2162) sailh.py:224-233                  */
+  void *rsoil;                 /* (B,nb) debug column, SPART.py:262-267      */
+  void *La;                    /* (B,nb) convolved ET radiance, SPART.py:183 */
+} spart_materialize;
+
+int spart_ctx_create(spart_ctx **out, int device, const spart_tables *tables);
+int spart_ctx_destroy(spart_ctx *ctx);
+const char *spart_last_error(const spart_ctx *ctx); /* ctx may be NULL: last creation error */
+
+int spart_ctx_nb(const spart_ctx *ctx);                    /* sensor bands of the context */
+int spart_ctx_econv(const spart_ctx *ctx, double *host_out); /* (nb,) SRF-convolved ET irradiance (SPART.py:389-394), copied to HOST */
+
+/* Bytes of scratch the batched entry points need for B samples (prelude constants + the
+ * canopy values at the sensor bands).  The same buffer may be reused by successive calls
+ * on one stream.  spart_smac_batch sizes its workspace with dtype = SPART_F64. */
+size_t spart_workspace_bytes(const spart_ctx *ctx, int dtype, int64_t B);
+
+/* PROSPECT_5D (prospect_5d.py:117-246).  leaf[9] = Cab, Cdm, Cw, Cs, Cca, Cant, N, PROT, CBC.
+ * Outputs (B,2001): refl, tran, kChlrel (any may be NULL). */
+int spart_prospect_batch(spart_ctx *ctx, int dtype, int64_t B, const double *const leaf[9], void *refl, void *tran,
+                         void *kchl, void *workspace, size_t workspace_bytes, void *stream);
+
+/* BSM + soilwat (bsm.py:17-128).  soil[6] = B, lat, lon, SMp, SMC, film.
+ * rdry_in: optional (B,2001) user dry spectra in `dtype` (the rdry_set branch, bsm.py:42-43).
+ * Outputs (B,2001): refl (wet), refl_dry. */
+int spart_bsm_batch(spart_ctx *ctx, int dtype, int64_t B, const double *const soil[6], const void *rdry_in,
+                    void *refl, void *refl_dry, void *workspace, size_t workspace_bytes, void *stream);
+
+/* calculate_leafangles (sailh.py:351-398): lidf (B,13) float64. */
+int spart_lidf_batch(spart_ctx *ctx, int64_t B, const double *LIDFa, const double *LIDFb, double *lidf, void *stream);
+
+/* SAILH (sailh.py:14-237).  rho, tau, rs: (B,2162) in `dtype`; canopy[4] = LAI, LIDFa, LIDFb, q;
+ * angles[3] = sol, obs, rel (degrees).  out4 = rso, rdo, rsd, rdd, each (B,2162). */
+int spart_sailh_batch(spart_ctx *ctx, int dtype, int64_t B, const void *rho, const void *tau, const void *rs,
+                      const double *const canopy[4], const double *const angles[3], void *const out4[4],
+                      void *workspace, size_t workspace_bytes, void *stream);
+
+/* SMAC (smac.py:14-213).  angles[3]; atm[4] = aot550, uo3, uh2o, Pa.  out9 (B,nb) float64 in the
+ * AtmosphericOptics order Ta_s, Ta_o, Tg, Ra_dd, Ra_so, Ta_ss, Ta_sd, Ta_oo, Ta_do (smac.py:209-211). */
+int spart_smac_batch(spart_ctx *ctx, int64_t B, const double *const angles[3], const double *const atm[4],
+                     double *const out9[9], void *workspace, size_t workspace_bytes, void *stream);
+
+/* SPART(...).run() for a fresh object per sample (SPART.py:162-269).
+ * params[27]: Cab Cdm Cw Cs Cca Cant N PROT CBC | B lat lon SMp SMC film | LAI LIDFa LIDFb q |
+ *             tts tto psi | aot550 uo3 uh2o Pa | DOY          (each (B,) float64)
+ * rho_thermal / tau_thermal: optional (B,) float64 (LeafBiology defaults 0.01 when NULL).
+ * Outputs (B,nb) in `dtype`. */
+int spart_run_batch(spart_ctx *ctx, int dtype, int64_t B, const double *const params[SPART_NPARAM],
+                    const double *rho_thermal, const double *tau_thermal, void *R_TOC, void *R_TOA, void *L_TOA,
+                    const spart_materialize *opt, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Measurement aid (bench.py): when enabled, spart_run_batch brackets its dominant kernel (the
+ * fused band kernel) with HIP events recorded on the caller's stream, for up to max_calls calls;
+ * spart_profile_read waits for them and returns the summed kernel time and the number of calls.
+ * max_calls = 0 disables. */
+int spart_profile_enable(spart_ctx *ctx, int max_calls);
+int spart_profile_read(spart_ctx *ctx, double *total_ms, int *ncalls);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPART_HIP_H */

@@ -1,0 +1,49 @@
+"""Build libspart_hip.so (the C-ABI library of include/spart_hip.h) in-tree with hipcc for gfx950.
+
+    python spart-python_amd/build.py [--fast-math] [--force]
+
+hipcc cross-compiles without a GPU.  The .so lands next to this file so that it travels with
+the source tree (it is git-ignored, not gpurun-ignored).
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc", "spart_capi.hip")
+DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("spart_kernels.h", "spart_math.h", "spart_e3_coeffs.h")] + [
+    os.path.join(HERE, "..", "include", "spart_hip.h")]
+OUT = os.path.join(HERE, "libspart_hip.so")
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def needs_build():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    return any(os.path.getmtime(d) > t for d in DEPS)
+
+
+def build(force=False, fast_math=None, verbose=True):
+    if fast_math is None:
+        fast_math = os.environ.get("SPART_FAST_MATH", "0") == "1"
+    if not force and not needs_build():
+        return OUT
+    cmd = [hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-o", OUT, SRC]
+    if fast_math:
+        cmd.insert(1, "-DSPART_FAST_MATH=1")
+    if verbose:
+        print("[spart_amd] " + " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, fast_math=True if "--fast-math" in sys.argv else None)
+    print(OUT)

@@ -1,0 +1,502 @@
+// libspart_hip.so: the C ABI declared in include/spart_hip.h (host side: context, table
+// derivation, workspace carving, kernel launches).  No torch types, no allocation on the
+// call path (graph-capturable), caller owns every buffer.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/spart_hip.h"
+#include "spart_kernels.h"
+
+using namespace spart;
+
+struct spart_ctx {
+  int device = 0;
+  float* tabF = nullptr;    // (NTAB, NWL)
+  double* tabD = nullptr;   // (NTAB, NWL)
+  double* Ea = nullptr;     // (NWL)
+  int nb = 0, nslot = 0;
+  int* need_slot = nullptr;  // (2048) eval index -> slot or -1
+  int* slot0 = nullptr;      // (nb)
+  int* slot1 = nullptr;      // (nb)
+  double* frac = nullptr;    // (nb)
+  double* coef = nullptr;    // (48, nb)
+  double* econv = nullptr;   // (nb)
+  std::vector<double> econv_host;
+  // optional timing of the dominant kernel (k_bands): event pairs recorded on the caller's stream
+  bool profile = false;
+  std::vector<hipEvent_t> ev;   // start0, stop0, start1, stop1, ...
+  size_t ev_used = 0;
+  mutable char err[512] = {0};
+};
+
+static thread_local char g_err[512] = {0};
+
+static int fail(const spart_ctx* ctx, int code, const char* fmt, ...) {
+  char* dst = ctx ? ctx->err : g_err;
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(dst, 512, fmt, ap);
+  va_end(ap);
+  if (ctx) std::snprintf(g_err, 512, "%s", dst);
+  return code;
+}
+
+#define HIP_TRY(ctx, call)                                                                              \
+  do {                                                                                                  \
+    hipError_t e_ = (call);                                                                             \
+    if (e_ != hipSuccess) return fail(ctx, SPART_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_));      \
+  } while (0)
+
+namespace {
+
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) ok = false;
+    if (ok && prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
+  }
+  ~DeviceGuard() {
+    int cur = -1;
+    if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+  }
+};
+
+inline size_t align_up(size_t x) { return (x + 255) & ~size_t(255); }
+
+struct Workspace {
+  size_t cst_off, atm_off, g_off, gs_off, total;
+};
+
+Workspace carve(int dtype, int64_t B, int nslot) {
+  size_t es = dtype == SPART_F64 ? 8 : 4;
+  Workspace w;
+  size_t o = 0;
+  w.cst_off = o; o = align_up(o + (size_t)B * NCONST * es);
+  w.atm_off = o; o = align_up(o + (size_t)B * NATM * 8);
+  w.g_off = o;   o = align_up(o + (size_t)B * (size_t)(nslot > 0 ? nslot : 1) * 4 * es);
+  w.gs_off = o;  o = align_up(o + (size_t)B * (size_t)(nslot > 0 ? nslot : 1) * es);
+  w.total = o;
+  return w;
+}
+
+int pick_chunk(int64_t B) {
+  // >= ~4096 workgroups when the batch allows it (256 CUs x 8 XCD-interleaved tiles), at most
+  // 64 samples per workgroup so that the table slice in VGPRs is amortised
+  int64_t c = (B * NTILE + 4095) / 4096;
+  if (c < 1) c = 1;
+  if (c > 64) c = 64;
+  return (int)c;
+}
+
+// np.interp(x, wlS, .) support points (SPART.py:220-223) on the 2162-point grid
+void wl_solar(std::vector<double>& wl) {
+  wl.clear();
+  for (int i = 400; i <= 2400; ++i) wl.push_back(i);
+  for (int i = 2500; i <= 15000; i += 100) wl.push_back(i);
+  for (int i = 16000; i <= 50000; i += 1000) wl.push_back(i);
+}
+
+template <typename T> int upload(const spart_ctx* ctx, T** dst, const std::vector<T>& src) {
+  HIP_TRY(ctx, hipMalloc((void**)dst, src.size() * sizeof(T)));
+  HIP_TRY(ctx, hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+  return SPART_OK;
+}
+
+template <typename T>
+int launch_prelude(spart_ctx* ctx, const ParamPtrs& pp, int mask, int64_t B, T* cst, double* atm, double* lidf,
+                   hipStream_t st) {
+  unsigned grid = (unsigned)((B + 255) / 256);
+  hipLaunchKernelGGL((k_prelude<T>), dim3(grid), dim3(256), 0, st, pp, mask, B, cst, atm, lidf);
+  HIP_TRY(ctx, hipGetLastError());
+  return SPART_OK;
+}
+
+}  // namespace
+
+template <typename T>
+static int prospect_impl(spart_ctx* ctx, int64_t B, const double* const leaf[9], void* refl, void* tran, void* kchl,
+                         char* wsp, const Workspace& ws, hipStream_t st) {
+  ParamPtrs pp;
+  std::memset(&pp, 0, sizeof(pp));
+  for (int i = 0; i < 9; ++i) pp.p[i] = leaf[i];
+  T* cst = (T*)(wsp + ws.cst_off);
+  int rc = launch_prelude<T>(ctx, pp, PRE_LEAF, B, cst, nullptr, nullptr, st);
+  if (rc) return rc;
+  int chunk = pick_chunk(B);
+  int64_t nchunk = (B + chunk - 1) / chunk;
+  const T* tab = sizeof(T) == 4 ? (const T*)ctx->tabF : (const T*)ctx->tabD;
+  hipLaunchKernelGGL((k_prospect<T>), dim3((unsigned)(nchunk * NTILE)), dim3(TILE), 0, st, tab, (const T*)cst, B, chunk,
+                     (T*)refl, (T*)tran, (T*)kchl);
+  HIP_TRY(ctx, hipGetLastError());
+  return SPART_OK;
+}
+
+template <typename T>
+static int bsm_impl(spart_ctx* ctx, int64_t B, const double* const soil[6], const void* rdry_in, void* refl, void* dry,
+                    char* wsp, const Workspace& ws, hipStream_t st) {
+  ParamPtrs pp;
+  std::memset(&pp, 0, sizeof(pp));
+  for (int i = 0; i < 6; ++i) pp.p[9 + i] = soil[i];
+  T* cst = (T*)(wsp + ws.cst_off);
+  int rc = launch_prelude<T>(ctx, pp, PRE_SOIL, B, cst, nullptr, nullptr, st);
+  if (rc) return rc;
+  int chunk = pick_chunk(B);
+  int64_t nchunk = (B + chunk - 1) / chunk;
+  const T* tab = sizeof(T) == 4 ? (const T*)ctx->tabF : (const T*)ctx->tabD;
+  hipLaunchKernelGGL((k_bsm<T>), dim3((unsigned)(nchunk * NTILE)), dim3(TILE), 0, st, tab, (const T*)cst, B, chunk,
+                     (const T*)rdry_in, (T*)refl, (T*)dry);
+  HIP_TRY(ctx, hipGetLastError());
+  return SPART_OK;
+}
+
+template <typename T>
+static int sailh_impl(spart_ctx* ctx, int64_t B, const void* rho, const void* tau, const void* rs,
+                      const double* const canopy[4], const double* const angles[3], void* const out4[4], char* wsp,
+                      const Workspace& ws, hipStream_t st) {
+  ParamPtrs pp;
+  std::memset(&pp, 0, sizeof(pp));
+  for (int i = 0; i < 4; ++i) pp.p[15 + i] = canopy[i];
+  for (int i = 0; i < 3; ++i) pp.p[19 + i] = angles[i];
+  T* cst = (T*)(wsp + ws.cst_off);
+  int rc = launch_prelude<T>(ctx, pp, PRE_CANOPY, B, cst, nullptr, nullptr, st);
+  if (rc) return rc;
+  int chunk = pick_chunk(B);
+  int64_t nchunk = (B + chunk - 1) / chunk;
+  hipLaunchKernelGGL((k_sailh<T>), dim3((unsigned)(nchunk * NTILE_FULL)), dim3(TILE), 0, st, (const T*)cst, B, chunk,
+                     (const T*)rho, (const T*)tau, (const T*)rs, (T*)out4[0], (T*)out4[1], (T*)out4[2], (T*)out4[3]);
+  HIP_TRY(ctx, hipGetLastError());
+  return SPART_OK;
+}
+
+template <typename T>
+static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_NPARAM], const double* rho_th,
+                    const double* tau_th, void* R_TOC, void* R_TOA, void* L_TOA, const spart_materialize* opt, char* wsp,
+                    const Workspace& ws, hipStream_t st) {
+  ParamPtrs pp;
+  for (int i = 0; i < NPARAM; ++i) pp.p[i] = params[i];
+  pp.rho_th = rho_th;
+  pp.tau_th = tau_th;
+  T* cst = (T*)(wsp + ws.cst_off);
+  double* atm = (double*)(wsp + ws.atm_off);
+  T* G = (T*)(wsp + ws.g_off);
+  T* gs = (T*)(wsp + ws.gs_off);
+  int rc = launch_prelude<T>(ctx, pp, PRE_ALL, B, cst, atm, nullptr, st);
+  if (rc) return rc;
+  int chunk = pick_chunk(B);
+  int64_t nchunk = (B + chunk - 1) / chunk;
+  const T* tab = sizeof(T) == 4 ? (const T*)ctx->tabF : (const T*)ctx->tabD;
+  MatPtrs<T> mp;
+  std::memset(&mp, 0, sizeof(mp));
+  bool mat = false;
+  if (opt) {
+    mp.leaf_refl = (T*)opt->leaf_refl; mp.leaf_tran = (T*)opt->leaf_tran; mp.leaf_kchl = (T*)opt->leaf_kchl;
+    mp.soil_refl = (T*)opt->soil_refl; mp.soil_dry = (T*)opt->soil_refl_dry;
+    mp.rso = (T*)opt->rso; mp.rdo = (T*)opt->rdo; mp.rsd = (T*)opt->rsd; mp.rdd = (T*)opt->rdd;
+    mp.gsoil = opt->rsoil ? gs : nullptr;
+    mat = mp.leaf_refl || mp.leaf_tran || mp.leaf_kchl || mp.soil_refl || mp.soil_dry || mp.rso || mp.rdo || mp.rsd ||
+          mp.rdd || mp.gsoil;
+  }
+  dim3 grid((unsigned)(nchunk * NTILE));
+  const bool prof = ctx->profile && ctx->ev_used + 2 <= ctx->ev.size();
+  if (prof) HIP_TRY(ctx, hipEventRecord(ctx->ev[ctx->ev_used], st));
+  if (mat)
+    hipLaunchKernelGGL((k_bands<T, true>), grid, dim3(TILE), 0, st, tab, (const T*)cst, (const int*)ctx->need_slot,
+                       ctx->nslot, G, B, chunk, mp);
+  else
+    hipLaunchKernelGGL((k_bands<T, false>), grid, dim3(TILE), 0, st, tab, (const T*)cst, (const int*)ctx->need_slot,
+                       ctx->nslot, G, B, chunk, mp);
+  HIP_TRY(ctx, hipGetLastError());
+  if (prof) {
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[ctx->ev_used + 1], st));
+    ctx->ev_used += 2;
+  }
+  if (mat) {
+    T* padded[] = {mp.leaf_refl, mp.leaf_tran, mp.soil_refl, mp.rso, mp.rdo, mp.rsd, mp.rdd};
+    int64_t n = B * (NWLT - 1);
+    for (T* a : padded)
+      if (a) {
+        hipLaunchKernelGGL((k_fill_thermal<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, B);
+        HIP_TRY(ctx, hipGetLastError());
+      }
+  }
+  SensorTab stb{ctx->slot0, ctx->slot1, ctx->frac, ctx->coef, ctx->econv, ctx->nb, ctx->nslot};
+  int64_t n = B * ctx->nb;
+  hipLaunchKernelGGL((k_sensor<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, stb, (const T*)G,
+                     (const double*)atm, B, (T*)R_TOC, (T*)R_TOA, (T*)L_TOA, (const T*)(opt && opt->rsoil ? gs : nullptr),
+                     (T*)(opt ? opt->rsoil : nullptr), (T*)(opt ? opt->La : nullptr));
+  HIP_TRY(ctx, hipGetLastError());
+  return SPART_OK;
+}
+
+extern "C" {
+
+const char* spart_last_error(const spart_ctx* ctx) { return ctx ? ctx->err : g_err; }
+
+int spart_ctx_nb(const spart_ctx* ctx) { return ctx ? ctx->nb : 0; }
+
+int spart_ctx_econv(const spart_ctx* ctx, double* host_out) {
+  if (!ctx || !host_out) return fail(ctx, SPART_ERR_INVALID, "spart_ctx_econv: null argument");
+  if (ctx->nb == 0) return fail(ctx, SPART_ERR_NOSENSOR, "context has no sensor");
+  std::memcpy(host_out, ctx->econv_host.data(), sizeof(double) * ctx->nb);
+  return SPART_OK;
+}
+
+int spart_ctx_destroy(spart_ctx* ctx) {
+  if (!ctx) return SPART_OK;
+  DeviceGuard g(ctx->device);
+  (void)hipFree(ctx->tabF); (void)hipFree(ctx->tabD); (void)hipFree(ctx->Ea); (void)hipFree(ctx->need_slot);
+  (void)hipFree(ctx->slot0); (void)hipFree(ctx->slot1); (void)hipFree(ctx->frac); (void)hipFree(ctx->coef);
+  (void)hipFree(ctx->econv);
+  for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
+  delete ctx;
+  return SPART_OK;
+}
+
+int spart_ctx_create(spart_ctx** out, int device, const spart_tables* t) {
+  if (!out || !t) return fail(nullptr, SPART_ERR_INVALID, "spart_ctx_create: null argument");
+  *out = nullptr;
+  const double* req[] = {t->nr, t->Kab, t->Kca, t->Kdm, t->Kw, t->Ks, t->Kant, t->cbc, t->prot, t->GSV, t->nw, t->Ea};
+  for (const double* p : req)
+    if (!p) return fail(nullptr, SPART_ERR_INVALID, "spart_ctx_create: a spectral table pointer is null");
+  if (t->nb < 0 || t->nb > MAX_NB) return fail(nullptr, SPART_ERR_INVALID, "spart_ctx_create: nb=%d out of range", t->nb);
+  if (t->nb > 0 && (!t->wl_smac || !t->coef || !t->wl_srf || !t->p_srf || t->nsrf <= 0))
+    return fail(nullptr, SPART_ERR_INVALID, "spart_ctx_create: sensor block incomplete");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(nullptr, SPART_ERR_HIP, "spart_ctx_create: no HIP device available (this library has no CPU path)");
+  if (device < 0 || device >= ndev) return fail(nullptr, SPART_ERR_INVALID, "spart_ctx_create: device %d of %d", device, ndev);
+  DeviceGuard guard(device);
+  if (!guard.ok) return fail(nullptr, SPART_ERR_HIP, "spart_ctx_create: cannot select device %d", device);
+
+  spart_ctx* ctx = new spart_ctx();
+  ctx->device = device;
+  // --- derived per-band tables, float64 on the host
+  std::vector<double> tab((size_t)NTAB * NWL);
+  const double tav90_2 = calculate_tav(90, 2.0);
+  for (int i = 0; i < NWL; ++i) {
+    tab[TAB_KAB * NWL + i] = t->Kab[i];
+    tab[TAB_KCA * NWL + i] = t->Kca[i];
+    tab[TAB_KDM * NWL + i] = t->Kdm[i];
+    tab[TAB_KW * NWL + i] = t->Kw[i];
+    tab[TAB_KS * NWL + i] = t->Ks[i];
+    tab[TAB_KANT * NWL + i] = t->Kant[i];
+    tab[TAB_CBC * NWL + i] = t->cbc[i];
+    tab[TAB_PROT * NWL + i] = t->prot[i];
+    double nr = t->nr[i], nw = t->nw[i];
+    double t12 = calculate_tav(90, nr);                         // prospect_5d.py:202
+    tab[TAB_TALF * NWL + i] = calculate_tav(40, nr);            // :200
+    tab[TAB_T12 * NWL + i] = t12;
+    tab[TAB_T21 * NWL + i] = t12 / (nr * nr);                   // :204
+    tab[TAB_GSV0 * NWL + i] = t->GSV[3 * i + 0];
+    tab[TAB_GSV1 * NWL + i] = t->GSV[3 * i + 1];
+    tab[TAB_GSV2 * NWL + i] = t->GSV[3 * i + 2];
+    tab[TAB_CBAC * NWL + i] = calculate_tav(90, 2.0 / nw) / tav90_2;   // bsm.py:111
+    tab[TAB_PW * NWL + i] = 1.0 - calculate_tav(90, nw) / (nw * nw);   // bsm.py:115
+    tab[TAB_RW * NWL + i] = 1.0 - calculate_tav(40, nw);               // bsm.py:119
+  }
+  std::vector<float> tabf(tab.begin(), tab.end());
+  int rc;
+  if ((rc = upload(ctx, &ctx->tabD, tab)) || (rc = upload(ctx, &ctx->tabF, tabf))) { std::snprintf(g_err, 512, "%s", ctx->err); spart_ctx_destroy(ctx); return rc; }
+  std::vector<double> ea(t->Ea, t->Ea + NWL);
+  if ((rc = upload(ctx, &ctx->Ea, ea))) { std::snprintf(g_err, 512, "%s", ctx->err); spart_ctx_destroy(ctx); return rc; }
+
+  // --- sensor block
+  ctx->nb = t->nb;
+  std::vector<int> need(NTILE * TILE, -1);
+  if (t->nb > 0) {
+    std::vector<double> wl;
+    wl_solar(wl);
+    std::vector<int> s0(t->nb), s1(t->nb);
+    std::vector<double> fr(t->nb);
+    int nslot = 0;
+    auto slot_of = [&](int grid_idx) {
+      int ev = grid_idx < NWL ? grid_idx : NWL;   // every thermal grid point holds the same value
+      if (need[ev] < 0) need[ev] = nslot++;
+      return need[ev];
+    };
+    for (int j = 0; j < t->nb; ++j) {
+      double x = t->wl_smac[j];
+      // i0 = last grid point <= x, clipped to [0, n-2]; np.interp clamps outside the grid
+      int i0 = 0;
+      while (i0 + 1 < (int)wl.size() - 1 && wl[i0 + 1] <= x) ++i0;
+      int i1 = i0 + 1;
+      double f = (x - wl[i0]) / (wl[i1] - wl[i0]);
+      if (!(f > 0.0)) f = 0.0;
+      if (f > 1.0) f = 1.0;
+      s0[j] = slot_of(i0);
+      s1[j] = f > 0.0 ? slot_of(i1) : s0[j];
+      fr[j] = f;
+    }
+    ctx->nslot = nslot;
+    std::vector<double> coef(t->coef, t->coef + (size_t)NCOEF * t->nb);
+    std::vector<double> wsrf(t->wl_srf, t->wl_srf + (size_t)t->nsrf * t->nb), psrf(t->p_srf, t->p_srf + (size_t)t->nsrf * t->nb);
+    double *d_w = nullptr, *d_p = nullptr;
+    std::vector<double> ec(t->nb, 0.0);
+    if ((rc = upload(ctx, &ctx->slot0, s0)) || (rc = upload(ctx, &ctx->slot1, s1)) || (rc = upload(ctx, &ctx->frac, fr)) ||
+        (rc = upload(ctx, &ctx->coef, coef)) || (rc = upload(ctx, &ctx->econv, ec)) || (rc = upload(ctx, &d_w, wsrf)) ||
+        (rc = upload(ctx, &d_p, psrf))) {
+      std::snprintf(g_err, 512, "%s", ctx->err);
+      (void)hipFree(d_w); (void)hipFree(d_p);
+      spart_ctx_destroy(ctx);
+      return rc;
+    }
+    // SRF convolution of the ET irradiance: one wave per sensor band (SPART.py:358-396)
+    hipLaunchKernelGGL(k_econv, dim3(t->nb), dim3(64), 0, 0, ctx->Ea, d_w, d_p, t->nsrf, t->nb, ctx->econv);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    ctx->econv_host.resize(t->nb);
+    if (e == hipSuccess) e = hipMemcpy(ctx->econv_host.data(), ctx->econv, sizeof(double) * t->nb, hipMemcpyDeviceToHost);
+    (void)hipFree(d_w); (void)hipFree(d_p);
+    if (e != hipSuccess) {
+      fail(nullptr, SPART_ERR_HIP, "spart_ctx_create: SRF convolution kernel: %s", hipGetErrorString(e));
+      spart_ctx_destroy(ctx);
+      return SPART_ERR_HIP;
+    }
+  }
+  if ((rc = upload(ctx, &ctx->need_slot, need))) { std::snprintf(g_err, 512, "%s", ctx->err); spart_ctx_destroy(ctx); return rc; }
+  *out = ctx;
+  return SPART_OK;
+}
+
+int spart_profile_enable(spart_ctx* ctx, int max_calls) {
+  if (!ctx) return fail(nullptr, SPART_ERR_INVALID, "spart_profile_enable: null context");
+  DeviceGuard guard(ctx->device);
+  ctx->profile = max_calls > 0;
+  ctx->ev_used = 0;
+  while (ctx->ev.size() < (size_t)(max_calls > 0 ? 2 * max_calls : 0)) {
+    hipEvent_t e;
+    HIP_TRY(ctx, hipEventCreate(&e));
+    ctx->ev.push_back(e);
+  }
+  return SPART_OK;
+}
+
+int spart_profile_read(spart_ctx* ctx, double* total_ms, int* ncalls) {
+  if (!ctx || !total_ms || !ncalls) return fail(ctx, SPART_ERR_INVALID, "spart_profile_read: null argument");
+  DeviceGuard guard(ctx->device);
+  double tot = 0.0;
+  int n = 0;
+  for (size_t i = 0; i + 1 < ctx->ev_used; i += 2) {
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev[i + 1]));
+    float ms = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]));
+    tot += ms;
+    ++n;
+  }
+  ctx->ev_used = 0;
+  *total_ms = tot;
+  *ncalls = n;
+  return SPART_OK;
+}
+
+size_t spart_workspace_bytes(const spart_ctx* ctx, int dtype, int64_t B) {
+  if (!ctx || B <= 0) return 0;
+  return carve(dtype, B, ctx->nslot).total;
+}
+
+#define CHECK_COMMON(name)                                                                                  \
+  if (!ctx) return fail(nullptr, SPART_ERR_INVALID, name ": null context");                                 \
+  if (dtype != SPART_F32 && dtype != SPART_F64) return fail(ctx, SPART_ERR_INVALID, name ": bad dtype %d", dtype); \
+  if (B < 0) return fail(ctx, SPART_ERR_INVALID, name ": negative batch");                                  \
+  if (B == 0) return SPART_OK;                                                                              \
+  Workspace ws = carve(dtype, B, ctx->nslot);                                                               \
+  if (!workspace || workspace_bytes < ws.total)                                                             \
+    return fail(ctx, SPART_ERR_WORKSPACE, name ": workspace of %zu bytes needed, %zu given", ws.total, workspace_bytes); \
+  DeviceGuard guard(ctx->device);                                                                           \
+  hipStream_t st = (hipStream_t)stream;                                                                     \
+  char* wsp = (char*)workspace;
+
+
+int spart_prospect_batch(spart_ctx* ctx, int dtype, int64_t B, const double* const leaf[9], void* refl, void* tran,
+                         void* kchl, void* workspace, size_t workspace_bytes, void* stream) {
+  CHECK_COMMON("spart_prospect_batch")
+  if (!leaf) return fail(ctx, SPART_ERR_INVALID, "spart_prospect_batch: null leaf");
+  for (int i = 0; i < 9; ++i)
+    if (!leaf[i]) return fail(ctx, SPART_ERR_INVALID, "spart_prospect_batch: leaf[%d] is null", i);
+  return dtype == SPART_F32 ? prospect_impl<float>(ctx, B, leaf, refl, tran, kchl, wsp, ws, st)
+                            : prospect_impl<double>(ctx, B, leaf, refl, tran, kchl, wsp, ws, st);
+}
+
+
+int spart_bsm_batch(spart_ctx* ctx, int dtype, int64_t B, const double* const soil[6], const void* rdry_in, void* refl,
+                    void* refl_dry, void* workspace, size_t workspace_bytes, void* stream) {
+  CHECK_COMMON("spart_bsm_batch")
+  if (!soil) return fail(ctx, SPART_ERR_INVALID, "spart_bsm_batch: null soil");
+  for (int i = 0; i < 6; ++i)
+    if (!soil[i] && !(rdry_in && i < 3)) return fail(ctx, SPART_ERR_INVALID, "spart_bsm_batch: soil[%d] is null", i);
+  return dtype == SPART_F32 ? bsm_impl<float>(ctx, B, soil, rdry_in, refl, refl_dry, wsp, ws, st)
+                            : bsm_impl<double>(ctx, B, soil, rdry_in, refl, refl_dry, wsp, ws, st);
+}
+
+int spart_lidf_batch(spart_ctx* ctx, int64_t B, const double* LIDFa, const double* LIDFb, double* lidf, void* stream) {
+  if (!ctx) return fail(nullptr, SPART_ERR_INVALID, "spart_lidf_batch: null context");
+  if (B < 0 || !LIDFa || !LIDFb || !lidf) return fail(ctx, SPART_ERR_INVALID, "spart_lidf_batch: bad argument");
+  if (B == 0) return SPART_OK;
+  DeviceGuard guard(ctx->device);
+  hipLaunchKernelGGL(k_lidf, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, LIDFa, LIDFb, B, lidf);
+  HIP_TRY(ctx, hipGetLastError());
+  return SPART_OK;
+}
+
+
+int spart_sailh_batch(spart_ctx* ctx, int dtype, int64_t B, const void* rho, const void* tau, const void* rs,
+                      const double* const canopy[4], const double* const angles[3], void* const out4[4],
+                      void* workspace, size_t workspace_bytes, void* stream) {
+  CHECK_COMMON("spart_sailh_batch")
+  if (!rho || !tau || !rs || !canopy || !angles || !out4) return fail(ctx, SPART_ERR_INVALID, "spart_sailh_batch: null argument");
+  for (int i = 0; i < 4; ++i)
+    if (!canopy[i] || !out4[i]) return fail(ctx, SPART_ERR_INVALID, "spart_sailh_batch: canopy/out4[%d] is null", i);
+  for (int i = 0; i < 3; ++i)
+    if (!angles[i]) return fail(ctx, SPART_ERR_INVALID, "spart_sailh_batch: angles[%d] is null", i);
+  return dtype == SPART_F32 ? sailh_impl<float>(ctx, B, rho, tau, rs, canopy, angles, out4, wsp, ws, st)
+                            : sailh_impl<double>(ctx, B, rho, tau, rs, canopy, angles, out4, wsp, ws, st);
+}
+
+int spart_smac_batch(spart_ctx* ctx, int64_t B, const double* const angles[3], const double* const atm[4],
+                     double* const out9[9], void* workspace, size_t workspace_bytes, void* stream) {
+  int dtype = SPART_F64;
+  CHECK_COMMON("spart_smac_batch")
+  if (ctx->nb == 0) return fail(ctx, SPART_ERR_NOSENSOR, "spart_smac_batch: context has no sensor");
+  if (!angles || !atm || !out9) return fail(ctx, SPART_ERR_INVALID, "spart_smac_batch: null argument");
+  for (int i = 0; i < 3; ++i) if (!angles[i]) return fail(ctx, SPART_ERR_INVALID, "spart_smac_batch: angles[%d] is null", i);
+  for (int i = 0; i < 4; ++i) if (!atm[i]) return fail(ctx, SPART_ERR_INVALID, "spart_smac_batch: atm[%d] is null", i);
+  for (int i = 0; i < 9; ++i) if (!out9[i]) return fail(ctx, SPART_ERR_INVALID, "spart_smac_batch: out9[%d] is null", i);
+  ParamPtrs pp;
+  std::memset(&pp, 0, sizeof(pp));
+  for (int i = 0; i < 3; ++i) pp.p[19 + i] = angles[i];
+  for (int i = 0; i < 4; ++i) pp.p[22 + i] = atm[i];
+  double* cst = (double*)(wsp + ws.cst_off);
+  double* a = (double*)(wsp + ws.atm_off);
+  int rc = launch_prelude<double>(ctx, pp, PRE_ATM, B, cst, a, nullptr, st);
+  if (rc) return rc;
+  Out9 o;
+  for (int i = 0; i < 9; ++i) o.o[i] = out9[i];
+  int64_t n = B * ctx->nb;
+  hipLaunchKernelGGL(k_smac, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)ctx->coef, ctx->nb,
+                     (const double*)a, B, o);
+  HIP_TRY(ctx, hipGetLastError());
+  return SPART_OK;
+}
+
+
+int spart_run_batch(spart_ctx* ctx, int dtype, int64_t B, const double* const params[SPART_NPARAM],
+                    const double* rho_thermal, const double* tau_thermal, void* R_TOC, void* R_TOA, void* L_TOA,
+                    const spart_materialize* opt, void* workspace, size_t workspace_bytes, void* stream) {
+  CHECK_COMMON("spart_run_batch")
+  if (ctx->nb == 0) return fail(ctx, SPART_ERR_NOSENSOR, "spart_run_batch: context has no sensor");
+  if (!params || !R_TOC || !R_TOA || !L_TOA) return fail(ctx, SPART_ERR_INVALID, "spart_run_batch: null argument");
+  for (int i = 0; i < SPART_NPARAM; ++i)
+    if (!params[i]) return fail(ctx, SPART_ERR_INVALID, "spart_run_batch: params[%d] is null", i);
+  return dtype == SPART_F32
+             ? run_impl<float>(ctx, B, params, rho_thermal, tau_thermal, R_TOC, R_TOA, L_TOA, opt, wsp, ws, st)
+             : run_impl<double>(ctx, B, params, rho_thermal, tau_thermal, R_TOC, R_TOA, L_TOA, opt, wsp, ws, st);
+}
+
+}  // extern "C"

@@ -1,0 +1,342 @@
+// HIP kernels of the SPART hot path for gfx950 (MI355X).
+//
+// Layout: the band axis is mapped onto lanes.  A workgroup of 256 lanes owns
+// 256 consecutive bands and walks a chunk of samples; each lane keeps ITS band's 17 table
+// values in VGPRs for the whole walk (the tables are read from memory once per workgroup,
+// coalesced along the band axis), while the per-sample constants are wave-uniform and
+// arrive through scalar loads from the prelude's workspace.  2001 optical bands + one
+// thermal evaluation (the 161 thermal bands are identical, SPART.py:427-470) fill
+// 2002 of the 2048 lanes of eight workgroups.
+#pragma once
+
+#include "spart_math.h"
+
+namespace spart {
+
+constexpr int TILE = 256;                 // lanes (= bands) per workgroup
+constexpr int NTILE = 8;                  // 8 * 256 = 2048 >= NEVAL
+constexpr int NTILE_FULL = 9;             // 9 * 256 >= 2162 (standalone SAILH: arbitrary thermal inputs)
+constexpr int MAX_NB = 64;
+
+struct ParamPtrs {
+  const double* p[NPARAM];
+  const double* rho_th;
+  const double* tau_th;
+};
+
+// ------------------------------------------------------------------------------------------
+// K1: one lane per sample, float64: parameters -> band constants + atmosphere scalars
+template <typename T>
+__global__ __launch_bounds__(256) void k_prelude(ParamPtrs pp, int mask, int64_t B, T* __restrict__ cst,
+                                                 double* __restrict__ atm, double* __restrict__ lidf) {
+  int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= B) return;
+  double p[NPARAM];
+#pragma unroll
+  for (int i = 0; i < NPARAM; ++i) p[i] = pp.p[i] ? pp.p[i][s] : 0.0;
+  double rho_th = pp.rho_th ? pp.rho_th[s] : 0.01;  // LeafBiology defaults (prospect_5d.py:82-83)
+  double tau_th = pp.tau_th ? pp.tau_th[s] : 0.01;
+  T c[NCONST];
+  double a[NATM];
+  double li[NLINCL];
+  sample_prelude<T>(p, rho_th, tau_th, mask, c, a, li);
+  // constants: 48 values per sample (written once, read by 8 workgroups through s_load)
+  T* dst = cst + s * NCONST;
+#pragma unroll
+  for (int i = 0; i < NCONST; ++i) dst[i] = c[i];
+  if (atm) {
+#pragma unroll
+    for (int i = 0; i < NATM; ++i) atm[s * NATM + i] = a[i];
+  }
+  if (lidf) {
+#pragma unroll
+    for (int i = 0; i < NLINCL; ++i) lidf[s * NLINCL + i] = li[i];
+  }
+}
+
+// leaf-angle distribution only (CanopyStructure.lidf, sailh.py:348)
+__global__ __launch_bounds__(256) void k_lidf(const double* __restrict__ a, const double* __restrict__ b, int64_t B,
+                                              double* __restrict__ lidf) {
+  int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= B) return;
+  double li[NLINCL];
+  leaf_angles(a[s], b[s], li);
+#pragma unroll
+  for (int i = 0; i < NLINCL; ++i) lidf[s * NLINCL + i] = li[i];
+}
+
+// ------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ BandTab<T> load_tab(const T* __restrict__ tab, int i) {
+  BandTab<T> t;
+  t.kab = tab[TAB_KAB * NWL + i];
+  t.kca = tab[TAB_KCA * NWL + i];
+  t.kdm = tab[TAB_KDM * NWL + i];
+  t.kw = tab[TAB_KW * NWL + i];
+  t.ks = tab[TAB_KS * NWL + i];
+  t.kant = tab[TAB_KANT * NWL + i];
+  t.kcbc = tab[TAB_CBC * NWL + i];
+  t.kprot = tab[TAB_PROT * NWL + i];
+  t.talf = tab[TAB_TALF * NWL + i];
+  t.t12 = tab[TAB_T12 * NWL + i];
+  t.t21 = tab[TAB_T21 * NWL + i];
+  t.g0 = tab[TAB_GSV0 * NWL + i];
+  t.g1 = tab[TAB_GSV1 * NWL + i];
+  t.g2 = tab[TAB_GSV2 * NWL + i];
+  t.cbac = tab[TAB_CBAC * NWL + i];
+  t.pw = tab[TAB_PW * NWL + i];
+  t.rw = tab[TAB_RW * NWL + i];
+  return t;
+}
+
+template <typename T> __device__ __forceinline__ CanopyPar<T> load_canopy(const T* __restrict__ c) {
+  CanopyPar<T> cp;
+  cp.sdb = c[C_SDB]; cp.sdf = c[C_SDF]; cp.ddb = c[C_DDB]; cp.ddf = c[C_DDF];
+  cp.dob = c[C_DOB]; cp.dof = c[C_DOF]; cp.sob = c[C_SOB]; cp.sof = c[C_SOF];
+  cp.bf = c[C_BF]; cp.ks = c[C_KS]; cp.ko = c[C_KO]; cp.lai = c[C_LAI];
+  cp.tss = c[C_TSS]; cp.too = c[C_TOO]; cp.Z = c[C_Z]; cp.hot = c[C_HOT]; cp.pso2w = c[C_PSO2W];
+  return cp;
+}
+
+template <typename T> struct MatPtrs {
+  T *leaf_refl, *leaf_tran, *leaf_kchl, *soil_refl, *soil_dry, *rso, *rdo, *rsd, *rdd;
+  T* gsoil;  // (B, nslot) wet soil at the sensor-band slots (debug column rsoil)
+};
+
+// ------------------------------------------------------------------------------------------
+// K2: the fused band kernel: PROSPECT + BSM + SAILH for every band of every sample.
+// grid.x = nchunk * NTILE (tile fastest), block = 256.
+// G receives rso, rdo, rsd, rdd at the bands the sensor needs: (B, nslot, 4).
+template <typename T, bool MAT>
+__global__ __launch_bounds__(TILE) void k_bands(const T* __restrict__ tab, const T* __restrict__ cst,
+                                                const int* __restrict__ need_slot, int nslot, T* __restrict__ G,
+                                                int64_t B, int chunk, MatPtrs<T> mat) {
+  const int tile = blockIdx.x % NTILE;
+  const int64_t ck = blockIdx.x / NTILE;
+  const int band = tile * TILE + threadIdx.x;          // 0..2047
+  const bool active = band < NEVAL;
+  const bool thermal = band == NWL;                    // the single thermal evaluation
+  const int ti = band < NWL ? band : NWL - 1;          // thermal soil = soil at 2400 nm (SPART.py:440)
+  const BandTab<T> tb = load_tab(tab, ti);
+  const int slot = active ? need_slot[band] : -1;
+  const int64_t s0 = ck * chunk;
+  const int64_t s1 = (s0 + chunk < B) ? s0 + chunk : B;
+  for (int64_t s = s0; s < s1; ++s) {
+    const T* __restrict__ c = cst + s * NCONST;        // wave-uniform -> scalar loads
+    T refl, tran, absb, K;
+    leaf_band<T>(tb, c[C_CAB], c[C_CCA], c[C_CDM], c[C_CW], c[C_CS], c[C_CANT], c[C_CBC], c[C_PROT], c[C_NM1], refl,
+                 tran, absb, K);
+    T rdry = soil_dry<T>(tb, c[C_F1], c[C_F2], c[C_F3]);
+    T fm[7] = {c[C_FM0], c[C_FM1], c[C_FM2], c[C_FM3], c[C_FM4], c[C_FM5], c[C_FM6]};
+    T rwet;
+    soil_band<T>(tb, rdry, c[C_WET], fm, c[C_FILM2], rwet);
+    T rho = thermal ? c[C_RHO_TH] : refl;              // SPART.py:463-466
+    T tau = thermal ? c[C_TAU_TH] : tran;
+    T ab = thermal ? (T(1) - c[C_RHO_TH] - c[C_TAU_TH]) : absb;
+    const CanopyPar<T> cp = load_canopy(c);
+    T rso, rdo, rsd, rdd;
+    canopy_band<T>(cp, rho, tau, ab, rwet, rso, rdo, rsd, rdd);
+    if (slot >= 0) {
+      T* g = G + (s * nslot + slot) * 4;
+      g[0] = rso; g[1] = rdo; g[2] = rsd; g[3] = rdd;
+    }
+    if (MAT) {
+      if (active) {
+        const int64_t o = s * NWLS + band;             // band 2001 = first thermal position
+        if (mat.leaf_refl) mat.leaf_refl[o] = rho;
+        if (mat.leaf_tran) mat.leaf_tran[o] = tau;
+        if (mat.soil_refl) mat.soil_refl[o] = rwet;
+        if (mat.rso) mat.rso[o] = rso;
+        if (mat.rdo) mat.rdo[o] = rdo;
+        if (mat.rsd) mat.rsd[o] = rsd;
+        if (mat.rdd) mat.rdd[o] = rdd;
+        if (!thermal) {
+          const int64_t o1 = s * NWL + band;
+          if (mat.leaf_kchl) mat.leaf_kchl[o1] = (K > T(0)) ? divx(c[C_CAB] * tb.kab, K) : T(0);  // prospect_5d.py:197-198
+          if (mat.soil_dry) mat.soil_dry[o1] = rdry;
+        }
+        if (mat.gsoil && slot >= 0) mat.gsoil[s * nslot + slot] = rwet;
+      }
+    }
+  }
+}
+
+// copy the thermal evaluation (position 2001) over the other 160 thermal bands
+template <typename T>
+__global__ __launch_bounds__(256) void k_fill_thermal(T* __restrict__ a, int64_t B) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t s = i / (NWLT - 1);
+  int j = (int)(i % (NWLT - 1));
+  if (s >= B) return;
+  a[s * NWLS + NWL + 1 + j] = a[s * NWLS + NWL];
+}
+
+// ------------------------------------------------------------------------------------------
+// standalone PROSPECT-5D / PRO: (B,2001) spectra out
+template <typename T>
+__global__ __launch_bounds__(TILE) void k_prospect(const T* __restrict__ tab, const T* __restrict__ cst, int64_t B,
+                                                   int chunk, T* __restrict__ o_refl, T* __restrict__ o_tran,
+                                                   T* __restrict__ o_kchl) {
+  const int tile = blockIdx.x % NTILE;
+  const int64_t ck = blockIdx.x / NTILE;
+  const int band = tile * TILE + threadIdx.x;
+  const bool active = band < NWL;
+  const BandTab<T> tb = load_tab(tab, active ? band : NWL - 1);
+  const int64_t s0 = ck * chunk;
+  const int64_t s1 = (s0 + chunk < B) ? s0 + chunk : B;
+  for (int64_t s = s0; s < s1; ++s) {
+    const T* __restrict__ c = cst + s * NCONST;
+    T refl, tran, absb, K;
+    leaf_band<T>(tb, c[C_CAB], c[C_CCA], c[C_CDM], c[C_CW], c[C_CS], c[C_CANT], c[C_CBC], c[C_PROT], c[C_NM1], refl,
+                 tran, absb, K);
+    if (active) {
+      const int64_t o = s * NWL + band;
+      if (o_refl) o_refl[o] = refl;
+      if (o_tran) o_tran[o] = tran;
+      if (o_kchl) o_kchl[o] = (K > T(0)) ? divx(c[C_CAB] * tb.kab, K) : T(0);
+    }
+  }
+}
+
+// standalone BSM: (B,2001) wet and dry soil spectra; optional user dry spectra (bsm.py:42-43)
+template <typename T>
+__global__ __launch_bounds__(TILE) void k_bsm(const T* __restrict__ tab, const T* __restrict__ cst, int64_t B,
+                                              int chunk, const T* __restrict__ rdry_in, T* __restrict__ o_refl,
+                                              T* __restrict__ o_dry) {
+  const int tile = blockIdx.x % NTILE;
+  const int64_t ck = blockIdx.x / NTILE;
+  const int band = tile * TILE + threadIdx.x;
+  const bool active = band < NWL;
+  const BandTab<T> tb = load_tab(tab, active ? band : NWL - 1);
+  const int64_t s0 = ck * chunk;
+  const int64_t s1 = (s0 + chunk < B) ? s0 + chunk : B;
+  for (int64_t s = s0; s < s1; ++s) {
+    const T* __restrict__ c = cst + s * NCONST;
+    T rdry = rdry_in ? (active ? rdry_in[s * NWL + band] : T(0)) : soil_dry<T>(tb, c[C_F1], c[C_F2], c[C_F3]);
+    T fm[7] = {c[C_FM0], c[C_FM1], c[C_FM2], c[C_FM3], c[C_FM4], c[C_FM5], c[C_FM6]};
+    T rwet;
+    soil_band<T>(tb, rdry, c[C_WET], fm, c[C_FILM2], rwet);
+    if (active) {
+      const int64_t o = s * NWL + band;
+      if (o_refl) o_refl[o] = rwet;
+      if (o_dry) o_dry[o] = rdry;
+    }
+  }
+}
+
+// standalone SAILH: leaf / soil spectra in, four canopy reflectance spectra out, all (B,2162)
+template <typename T>
+__global__ __launch_bounds__(TILE) void k_sailh(const T* __restrict__ cst, int64_t B, int chunk,
+                                                const T* __restrict__ i_rho, const T* __restrict__ i_tau,
+                                                const T* __restrict__ i_rs, T* __restrict__ o_rso,
+                                                T* __restrict__ o_rdo, T* __restrict__ o_rsd, T* __restrict__ o_rdd) {
+  const int tile = blockIdx.x % NTILE_FULL;
+  const int64_t ck = blockIdx.x / NTILE_FULL;
+  const int band = tile * TILE + threadIdx.x;
+  const bool active = band < NWLS;
+  const int64_t s0 = ck * chunk;
+  const int64_t s1 = (s0 + chunk < B) ? s0 + chunk : B;
+  for (int64_t s = s0; s < s1; ++s) {
+    const T* __restrict__ c = cst + s * NCONST;
+    const int64_t o = s * NWLS + (active ? band : 0);
+    T rho = i_rho[o], tau = i_tau[o], rs = i_rs[o];
+    const CanopyPar<T> cp = load_canopy(c);
+    T rso, rdo, rsd, rdd;
+    canopy_band<T>(cp, rho, tau, T(1) - rho - tau, rs, rso, rdo, rsd, rdd);
+    if (active) {
+      o_rso[o] = rso; o_rdo[o] = rdo; o_rsd[o] = rsd; o_rdd[o] = rdd;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K3: one lane per (sample, sensor band): np.interp to the band centre (SPART.py:220-223),
+// SMAC (smac.py), TOC -> TOA (SPART.py:243-252).  float64 arithmetic, outputs in T.
+struct SensorTab {
+  const int* slot0;      // (nb) slot of the grid point at/below the centre
+  const int* slot1;      // (nb) slot of the next grid point
+  const double* frac;    // (nb)
+  const double* coef;    // (48, nb)
+  const double* econv;   // (nb)
+  int nb, nslot;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_sensor(SensorTab st, const T* __restrict__ G, const double* __restrict__ atm,
+                                                int64_t B, T* __restrict__ R_TOC, T* __restrict__ R_TOA,
+                                                T* __restrict__ L_TOA, const T* __restrict__ gsoil,
+                                                T* __restrict__ o_rsoil, T* __restrict__ o_La) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * st.nb) return;
+  int64_t s = i / st.nb;
+  int j = (int)(i - s * st.nb);
+  const T* g0 = G + (s * st.nslot + st.slot0[j]) * 4;
+  const T* g1 = G + (s * st.nslot + st.slot1[j]) * 4;
+  double f = st.frac[j];
+  double v[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    double y0 = (double)g0[q], y1 = (double)g1[q];
+    v[q] = y0 + (y1 - y0) * f;
+  }
+  const double* a = atm + s * NATM;
+  SmacOut so = smac_band(a, st.coef + j, st.nb);
+  double La = a[A_LAF] * st.econv[j];     // SPART.py:353, 394
+  double rtoc, rtoa, ltoa;
+  toc_to_toa(so, v[0], v[1], v[3], v[2], La, rtoc, rtoa, ltoa);  // G order: rso, rdo, rsd, rdd
+  R_TOC[i] = (T)rtoc;
+  R_TOA[i] = (T)rtoa;
+  L_TOA[i] = (T)ltoa;
+  if (o_rsoil && gsoil) {
+    double y0 = (double)gsoil[s * st.nslot + st.slot0[j]], y1 = (double)gsoil[s * st.nslot + st.slot1[j]];
+    o_rsoil[i] = (T)(y0 + (y1 - y0) * f);
+  }
+  if (o_La) o_La[i] = (T)La;
+}
+
+// standalone SMAC: nine (B,nb) float64 outputs
+struct Out9 {
+  double* o[9];
+};
+__global__ __launch_bounds__(256) void k_smac(const double* __restrict__ coef, int nb, const double* __restrict__ atm,
+                                              int64_t B, Out9 out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * nb) return;
+  int64_t s = i / nb;
+  int j = (int)(i - s * nb);
+  SmacOut so = smac_band(atm + s * NATM, coef + j, nb);
+  out.o[0][i] = so.Ta_s; out.o[1][i] = so.Ta_o; out.o[2][i] = so.Tg; out.o[3][i] = so.Ra_dd; out.o[4][i] = so.Ra_so;
+  out.o[5][i] = so.Ta_ss; out.o[6][i] = so.Ta_sd; out.o[7][i] = so.Ta_oo; out.o[8][i] = so.Ta_do;
+}
+
+// ------------------------------------------------------------------------------------------
+// Context-creation kernel: SRF convolution of the extraterrestrial irradiance
+// (calculate_spectral_convolution, SPART.py:358-396).  One wave per sensor band; lanes stride
+// over the SRF samples, then a 64-lane shuffle reduction of sum(Ea[idx] p) and sum(p).
+__global__ __launch_bounds__(64) void k_econv(const double* __restrict__ Ea, const double* __restrict__ wl_srf,
+                                              const double* __restrict__ p_srf, int nsrf, int nb,
+                                              double* __restrict__ econv) {
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x;
+  double num = 0.0, den = 0.0;
+  for (int i = lane; i < nsrf; i += 64) {
+    double w = wl_srf[(size_t)i * nb + b];
+    double p = p_srf[(size_t)i * nb + b];
+    // nearest grid wavelength, ties to the lower one; NaN -> index 0 (numpy argmin over NaNs), SPART.py:381-387
+    int idx = 0;
+    if (w == w) {
+      double r = ::ceil(w - 0.5) - 400.0;
+      r = r < 0.0 ? 0.0 : (r > (double)(NWL - 1) ? (double)(NWL - 1) : r);
+      idx = (int)r;
+    }
+    num += Ea[idx] * p;
+    den += p;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    num += __shfl_down(num, off, 64);
+    den += __shfl_down(den, off, 64);
+  }
+  if (lane == 0) econv[b] = num / den;
+}
+
+}  // namespace spart

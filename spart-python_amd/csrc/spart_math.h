@@ -1,0 +1,693 @@
+// SPART hot path: per-band and per-sample arithmetic, shared by every kernel.
+//
+// Everything here is a plain templated inline function of registers (no memory traffic, no
+// thread indexing), so the same code is compiled by hipcc for gfx950 (the product) and by
+// g++ for the CPU-side arithmetic checks in tests/hostmath (test infrastructure only).
+//
+// The formulas are algebraic rearrangements of the reference's (file:line cited at each
+// function) chosen so that float32 keeps ~1e-6 relative accuracy where the reference's
+// literal float64 forms would cancel catastrophically:
+//   * leaf plate transmittance  tau = (1-K)e^-K + K^2 E1(K) == 2 E3(K)  evaluated from
+//     fitted forms that also return u = 1 - tau without cancellation,
+//   * every "1 - r - t" absorptance of the plate model is carried analytically,
+//   * Stokes N-layer terms are divided through by b^(2(N-1)) (no overflow),
+//   * SAIL: m^2 = a^2 - sigb^2 == (1 - rho - tau)(a + sigb),  rinf == sigb / (a + m),
+//     J1/J2 through phi(d) = (1 - e^-d)/d.
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define SPART_HD __host__ __device__ __forceinline__
+#else
+#define SPART_HD inline
+#endif
+
+#if defined(__clang__)
+// sample-level double arithmetic must round exactly like the reference's (e.g. the hot-spot
+// test dso == 0, sailh.py:78,120): no FMA contraction there
+#define SPART_NO_CONTRACT _Pragma("clang fp contract(off)")
+#else
+#define SPART_NO_CONTRACT
+#endif
+
+#include "spart_e3_coeffs.h"
+
+namespace spart {
+
+constexpr int NWL = 2001;    // 400..2400 nm, 1 nm          (SPART.py:303)
+constexpr int NWLT = 161;    // thermal pad                  (SPART.py:307-309)
+constexpr int NWLS = 2162;   // NWL + NWLT                   (SPART.py:310)
+constexpr int NLAYER = 60;   // canopy layers                (sailh.py:345)
+constexpr int NLINCL = 13;   // leaf inclination classes     (sailh.py:346)
+constexpr int NEVAL = 2002;  // band evaluations per spectrum: 2001 optical + ONE thermal (all 161 are identical)
+constexpr int NPARAM = 27;
+constexpr int NCOEF = 48;    // SMAC coefficient rows used   (smac.py:44-92)
+
+constexpr double PI = 3.14159265358979323846;
+
+// ------------------------------------------------------------------------------------------
+// scalar math wrappers
+template <typename T> struct Mx;
+
+template <> struct Mx<float> {
+  static SPART_HD float exp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(SPART_FAST_MATH)
+    return __expf(x);
+#else
+    return ::expf(x);
+#endif
+  }
+  static SPART_HD float log(float x) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(SPART_FAST_MATH)
+    return __logf(x);
+#else
+    return ::logf(x);
+#endif
+  }
+  static SPART_HD float sqrt(float x) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(SPART_FAST_MATH)
+    return __builtin_amdgcn_sqrtf(x);
+#else
+    return ::sqrtf(x);
+#endif
+  }
+  static SPART_HD float rcp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(SPART_FAST_MATH)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+  }
+  static SPART_HD float log1p(float x) { return ::log1pf(x); }
+  static SPART_HD float expm1(float x) { return ::expm1f(x); }
+  static SPART_HD float fabs(float x) { return ::fabsf(x); }
+  static SPART_HD float fmax(float a, float b) { return ::fmaxf(a, b); }
+  static SPART_HD float fmin(float a, float b) { return ::fminf(a, b); }
+  static SPART_HD float tiny() { return 1e-30f; }
+};
+
+template <> struct Mx<double> {
+  static SPART_HD double exp(double x) { return ::exp(x); }
+  static SPART_HD double log(double x) { return ::log(x); }
+  static SPART_HD double sqrt(double x) { return ::sqrt(x); }
+  static SPART_HD double rcp(double x) { return 1.0 / x; }
+  static SPART_HD double log1p(double x) { return ::log1p(x); }
+  static SPART_HD double expm1(double x) { return ::expm1(x); }
+  static SPART_HD double fabs(double x) { return ::fabs(x); }
+  static SPART_HD double fmax(double a, double b) { return ::fmax(a, b); }
+  static SPART_HD double fmin(double a, double b) { return ::fmin(a, b); }
+  static SPART_HD double tiny() { return 1e-300; }
+};
+
+template <typename T> SPART_HD T divx(T a, T b) { return a * Mx<T>::rcp(b); }
+
+// phi(d) = (1 - e^-d) / d   (-> 1 as d -> 0); the building block of the SAIL J-functions
+template <typename T> SPART_HD T phi_fn(T d) {
+  const T small = T(1e-10);  // expm1 is accurate for every d != 0; this only removes 0/0
+  T safe = (Mx<T>::fabs(d) < small) ? T(1) : d;
+  T v = -Mx<T>::expm1(-safe) * Mx<T>::rcp(safe);
+  return (Mx<T>::fabs(d) < small) ? (T(1) - T(0.5) * d) : v;
+}
+
+// ------------------------------------------------------------------------------------------
+// tau(K) = (1-K) exp(-K) + K^2 E1(K) = 2 E3(K)           (prospect_5d.py:183-196)
+// returns tau and u = 1 - tau; K <= 0 -> tau = 1 (prospect_5d.py:195)
+template <typename T> struct E3c;
+template <> struct E3c<float> {
+  static constexpr int GD = E3_G_DEG_F32, WD = E3_W_DEG_F32;
+  static SPART_HD float g(int i) { return E3_G_F32[i]; }
+  static SPART_HD float p(int i) { return E3_P_F32[i]; }
+  static SPART_HD float q(int i) { return E3_Q_F32[i]; }
+};
+template <> struct E3c<double> {
+  static constexpr int GD = E3_G_DEG_F64, WD = E3_W_DEG_F64;
+  static SPART_HD double g(int i) { return E3_G_F64[i]; }
+  static SPART_HD double p(int i) { return E3_P_F64[i]; }
+  static SPART_HD double q(int i) { return E3_Q_F64[i]; }
+};
+
+template <typename T> SPART_HD void plate_tau(T K, T& tau, T& u) {
+  using C = E3c<T>;
+  // small branch, evaluated at min(K,1)
+  T xs = Mx<T>::fmin(Mx<T>::fmax(K, Mx<T>::tiny()), T(1));
+  T g = C::g(C::GD);
+#pragma unroll
+  for (int i = C::GD - 1; i >= 0; --i) g = g * xs + C::g(i);
+  T us = xs * (g + xs * Mx<T>::log(xs));
+  // large branch, evaluated at t = 1/max(K,1)
+  T xl = Mx<T>::fmax(K, T(1));
+  T t = Mx<T>::rcp(xl);
+  T pn = C::p(C::WD), qn = C::q(C::WD);
+#pragma unroll
+  for (int i = C::WD - 1; i >= 0; --i) {
+    pn = pn * t + C::p(i);
+    qn = qn * t + C::q(i);
+  }
+  T tl = Mx<T>::exp(-xl) * (T(2) * t) * pn * Mx<T>::rcp((T(1) + T(3) * t) * qn);
+  bool small = K < T(1);
+  u = small ? us : (T(1) - tl);
+  tau = small ? (T(1) - us) : tl;
+  if (!(K > T(0))) {  // K <= 0 (NaN stays NaN through the arithmetic above)
+    bool isnan_ = (K != K);
+    tau = isnan_ ? K : T(1);
+    u = isnan_ ? K : T(0);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// calculate_tav (prospect_5d.py:249-311), double only: used once per context for the
+// table-only interface transmissivities
+inline double calculate_tav(double alpha, double nr) {
+  const double rd = PI / 180.0;
+  double n2 = nr * nr, n_p = n2 + 1, nm = n2 - 1;
+  double a = (nr + 1) * (nr + 1) / 2;
+  double k = -(n2 - 1) * (n2 - 1) / 4;
+  double sa = std::sin(alpha * rd);
+  double b1 = 0;
+  if (alpha != 90) b1 = std::sqrt((sa * sa - n_p / 2) * (sa * sa - n_p / 2) + k);
+  double b2 = sa * sa - n_p / 2;
+  double b = b1 - b2;
+  double b3 = b * b * b, a3 = a * a * a;
+  double ts = (k * k / (6 * b3) + k / b - b / 2) - (k * k / (6 * a3) + k / a - a / 2);
+  double tp1 = -2 * n2 * (b - a) / (n_p * n_p);
+  double tp2 = -2 * n2 * n_p * std::log(b / a) / (nm * nm);
+  double tp3 = n2 * (1 / b - 1 / a) / 2;
+  double tp4 = 16 * n2 * n2 * (n2 * n2 + 1) * std::log((2 * n_p * b - nm * nm) / (2 * n_p * a - nm * nm)) /
+               (n_p * n_p * n_p * nm * nm);
+  double tp5 = 16 * n2 * n2 * n2 * (1 / (2 * n_p * b - nm * nm) - 1 / (2 * n_p * a - nm * nm)) / (n_p * n_p * n_p);
+  return (ts + tp1 + tp2 + tp3 + tp4 + tp5) / (2 * sa * sa);
+}
+
+// ------------------------------------------------------------------------------------------
+// per-band table slice (lives in registers for the whole sample loop)
+// row order of the device table block ctx->tab[NTAB][NWL]
+enum TabRow {
+  TAB_KAB = 0, TAB_KCA, TAB_KDM, TAB_KW, TAB_KS, TAB_KANT, TAB_CBC, TAB_PROT,  // prospect_5d.py:158-167
+  TAB_TALF, TAB_T12, TAB_T21,   // tav(40,nr), tav(90,nr), tav(90,nr)/nr^2   (prospect_5d.py:200-205)
+  TAB_GSV0, TAB_GSV1, TAB_GSV2,  // bsm.py:45
+  TAB_CBAC, TAB_PW, TAB_RW,      // tav(90,2/nw)/tav(90,2), 1-tav(90,nw)/nw^2, 1-tav(40,nw) (bsm.py:110-119)
+  NTAB
+};
+
+template <typename T> struct BandTab {
+  T kab, kca, kdm, kw, ks, kant, kcbc, kprot, talf, t12, t21, g0, g1, g2, cbac, pw, rw;
+};
+
+// ------------------------------------------------------------------------------------------
+// per-sample constants consumed by the band kernels (written by the prelude kernel,
+// read through wave-uniform scalar loads).  Layout = array of NCONST values of T.
+enum ConstIdx {
+  // leaf: concentrations already divided by N (prospect_5d.py:170-179)
+  C_CAB = 0, C_CCA, C_CDM, C_CW, C_CS, C_CANT, C_CBC, C_PROT, C_NM1, C_RHO_TH, C_TAU_TH,
+  // soil (bsm.py:49-52, 101, 121-122)
+  C_F1, C_F2, C_F3, C_WET, C_FM0, C_FM1, C_FM2, C_FM3, C_FM4, C_FM5, C_FM6, C_FILM2,
+  // canopy (sailh.py:93-105, 200-203, 216, 219)
+  C_SDB, C_SDF, C_DDB, C_DDF, C_DOB, C_DOF, C_SOB, C_SOF, C_BF, C_KS, C_KO, C_LAI,
+  C_TSS, C_TOO, C_Z, C_HOT, C_PSO2W,
+  C_RSV0, C_RSV1, C_RSV2, C_RSV3, C_RSV4, C_RSV5, C_RSV6, C_RSV7,
+  NCONST  // 48
+};
+static_assert(NCONST == 48, "constant block is 48 values");
+
+// per-sample atmosphere scalars (double), read by the sensor-band kernel
+enum AtmIdx {
+  A_US = 0, A_UV, A_M, A_PEQ, A_PA, A_AOT, A_UO3, A_UH2O, A_CKSI, A_KSID, A_LAF, A_RSV,
+  NATM  // 12
+};
+
+// ------------------------------------------------------------------------------------------
+// PROSPECT-5D / PRO, one band                                        (prospect_5d.py:170-241)
+// cN[] = concentrations / N.  Returns refl, tran, absorptance = 1 - refl - tran, K = Kall.
+template <typename T>
+SPART_HD void leaf_band(const BandTab<T>& tb, T cab, T cca, T cdm, T cw, T cs, T cant, T cbc, T prot, T nm1,
+                        T& refl, T& tran, T& absb, T& Kall) {
+  T K = cab * tb.kab + cca * tb.kca + cdm * tb.kdm + cw * tb.kw + cs * tb.ks + cant * tb.kant + cbc * tb.kcbc +
+        prot * tb.kprot;  // :170-179
+  Kall = K;
+  T tau, u;
+  plate_tau(K, tau, u);  // :182-196
+  T r21 = T(1) - tb.t21, r12 = T(1) - tb.t12, ralf = T(1) - tb.talf;  // :201-205
+  T x = r21 * tau;
+  T inv = Mx<T>::rcp(T(1) - x * x);  // :208
+  T c = tau * tb.t21 * inv;
+  T Ta = tb.talf * c;   // :209
+  T Ra = ralf + x * Ta;  // :210
+  T t = tb.t12 * c;      // :213
+  T r = r12 + x * t;     // :214
+  // 1 - r - t = t12 (1-tau)/(1 - r21 tau);  1 - Ra - Ta = talf (1-tau)/(1 - r21 tau)
+  T gq = u * Mx<T>::rcp(T(1) - x);
+  T a1 = tb.t12 * gq;
+  T atop = tb.talf * gq;
+  // Stokes system for the N-1 lower layers (:219-230), written in a-1, b-1 and b^-(N-1)
+  T tt = Mx<T>::fmax(t, Mx<T>::tiny());
+  T D = Mx<T>::sqrt((T(1) + r + tt) * (T(1) + r - tt) * (T(1) - r + tt) * a1);  // :219
+  T am1 = (a1 * (T(1) - r + tt) + D) * Mx<T>::rcp(T(2) * r);   // a - 1, a from :222
+  T bm1 = (a1 * (T(1) - tt + r) + D) * Mx<T>::rcp(T(2) * tt);  // b - 1, b from :223
+  T a = T(1) + am1;
+  T z = nm1 * Mx<T>::log1p(bm1);  // (N-1) ln b
+  T sq = Mx<T>::exp(-z);          // b^-(N-1)
+  T omsq = -Mx<T>::expm1(-z);     // 1 - b^-(N-1)
+  T omq = omsq * (T(1) + sq);     // 1 - b^-2(N-1)
+  T A2 = am1 * (a + T(1));        // a^2 - 1
+  T iden = Mx<T>::rcp(A2 + omq);  // b^-2(N-1) (a^2 b^2(N-1) - 1)
+  T Rsub = a * omq * iden;        // :229
+  T Tsub = sq * A2 * iden;        // :230
+  T asub = am1 * omsq * (a - sq) * iden;  // 1 - Rsub - Tsub
+  if (!(a1 > T(0))) {             // zero absorption, r + t >= 1 (:233-235)
+    T tz = divx(t, t + (T(1) - t) * nm1);
+    bool nanv = (a1 != a1);
+    Tsub = nanv ? a1 : tz;
+    Rsub = nanv ? a1 : (T(1) - tz);
+    asub = nanv ? a1 : T(0);
+  }
+  T dd = Mx<T>::rcp(T(1) - Rsub * r);  // :239
+  tran = Ta * Tsub * dd;               // :240
+  refl = Ra + Ta * Rsub * t * dd;      // :241
+  absb = atop + Ta * (asub + Rsub * a1) * dd;
+}
+
+// ------------------------------------------------------------------------------------------
+// BSM + soilwat, one band                                        (bsm.py:49-52, 99-124)
+template <typename T>
+SPART_HD void soil_band(const BandTab<T>& tb, T rdry, T wet, const T fm[7], T film2, T& rwet) {
+  T rbac = T(1) - (T(1) - rdry) * (rdry * tb.cbac + T(1) - rdry);  // :110-112
+  T tw1 = Mx<T>::exp(-film2 * tb.kw);                              // :122 with k = 1
+  T tw = T(1);
+  T acc = rdry * fm[0];                                            // :124
+  T c1 = (T(1) - tb.rw) * (T(1) - tb.pw);
+#pragma unroll
+  for (int k = 1; k <= 6; ++k) {
+    tw *= tw1;
+    T x = tw * rbac;
+    T Rk = tb.rw + c1 * x * Mx<T>::rcp(T(1) - tb.pw * x);          // :123
+    acc += Rk * fm[k];
+  }
+  rwet = (wet > T(0)) ? acc : rdry;                                // :102-103
+}
+
+template <typename T> SPART_HD T soil_dry(const BandTab<T>& tb, T f1, T f2, T f3) {
+  return f1 * tb.g0 + f2 * tb.g1 + f3 * tb.g2;                     // bsm.py:52
+}
+
+// ------------------------------------------------------------------------------------------
+// SAILH, one band                                                  (sailh.py:142-233)
+template <typename T> struct CanopyPar {
+  T sdb, sdf, ddb, ddf, dob, dof, sob, sof, bf, ks, ko, lai, tss, too, Z, hot, pso2w;
+};
+
+template <typename T>
+SPART_HD void canopy_band(const CanopyPar<T>& c, T rho, T tau, T absb, T rs, T& rso, T& rdo, T& rsd, T& rdd) {
+  T sigb = c.ddb * rho + c.ddf * tau;  // :142-148
+  T sigf = c.ddf * rho + c.ddb * tau;
+  T sb = c.sdb * rho + c.sdf * tau;
+  T sf = c.sdf * rho + c.sdb * tau;
+  T vb = c.dob * rho + c.dof * tau;
+  T vf = c.dof * rho + c.dob * tau;
+  T w = c.sob * rho + c.sof * tau;
+  T a = T(1) - sigf;                   // :149
+  // m^2 = a^2 - sigb^2 = (a - sigb)(a + sigb), a - sigb = 1 - rho - tau   (:150)
+  T m = Mx<T>::sqrt(absb * (a + sigb));
+  T rinf = sigb * Mx<T>::rcp(a + m);   // == (a - m)/sigb   (:151)
+  T rinf2 = rinf * rinf;
+  T L = c.lai;
+  // J1(-1) = (e^-mL - e^-kL)/(k - m) = L e^-kL phi((m-k)L)   (:154-170, 180-183)
+  T J1k = L * c.tss * phi_fn((m - c.ks) * L);
+  T J1K = L * c.too * phi_fn((m - c.ko) * L);
+  // J2(0) = (1 - e^-kL e^-mL)/(k + m) = L phi((k+m)L)        (:172-177)
+  T J2k = L * phi_fn((c.ks + m) * L);
+  T J2K = L * phi_fn((c.ko + m) * L);
+  T e1 = Mx<T>::exp(-m * L);           // :185-189
+  T e2 = e1 * e1;
+  T re = rinf * e1;
+  T iden = Mx<T>::rcp(T(1) - rinf2 * rinf2);  // sic: 1 - rinf2**2 (:189)
+  T s1 = sf + rinf * sb;               // :191-198
+  T s2 = sf * rinf + sb;
+  T v1 = vf + rinf * vb;
+  T v2 = vf * rinf + vb;
+  T Pss = s1 * J1k, Qss = s2 * J2k, Poo = v1 * J1K, Qoo = v2 * J2K;
+  T tau_dd = (T(1) - rinf2) * e1 * iden;  // :205-210
+  T rho_dd = rinf * (T(1) - e2) * iden;
+  T tau_sd = (Pss - re * Qss) * iden;
+  T tau_do = (Poo - re * Qoo) * iden;
+  T rho_sd = (Qss - re * Pss) * iden;
+  T rho_do = (Qoo - re * Poo) * iden;
+  T T1 = v2 * s1 * (c.Z - J1k * c.too) * Mx<T>::rcp(c.ko + m) +
+         v1 * s2 * (c.Z - J1K * c.tss) * Mx<T>::rcp(c.ks + m);  // :212
+  T T2 = -(Qoo * rho_sd + Poo * tau_sd) * rinf;                   // :213
+  T rho_sod = (T1 + T2) * Mx<T>::rcp(T(1) - rinf2);               // :214
+  T rho_so = rho_sod + w * c.hot;                                 // :216-217
+  T idn = Mx<T>::rcp(T(1) - rs * rho_dd);                         // :222
+  rso = rho_so + rs * c.pso2w +
+        ((tau_sd + c.tss * rs * rho_dd) * c.too + (tau_sd + c.tss) * tau_do) * rs * idn;  // :224-230
+  rdo = rho_do + (c.too + tau_do) * rs * tau_dd * idn;            // :231
+  rsd = rho_sd + (c.tss + tau_sd) * rs * tau_dd * idn;            // :232
+  rdd = rho_dd + tau_dd * rs * tau_dd * idn;                      // :233
+}
+
+// ------------------------------------------------------------------------------------------
+// sample-level (band independent) arithmetic: always double
+// ------------------------------------------------------------------------------------------
+
+// calculate_leafangles.dcum (sailh.py:368-384)
+SPART_HD double lidf_dcum(double a, double b, double theta_deg) {
+  const double rd = PI / 180.0;
+  if (a > 1.0) return 1.0 - ::cos(theta_deg * rd);  // :371-372
+  double x = 2.0 * rd * theta_deg;
+  const double theta2 = x;
+  double y = 0.0, dx;
+  int it = 0;
+  do {  // :378-382; the cap only guards against non-convergence for non-physical |a|+|b| >> 1
+    y = a * ::sin(x) + 0.5 * b * ::sin(2.0 * x);
+    dx = 0.5 * (y - x + theta2);
+    x += dx;
+  } while (::fabs(dx) > 1e-8 && ++it < 100000);
+  return (2.0 * y + theta2) / PI;
+}
+
+// F(theta_i) nodes: 10..80 step 10, 82..88 step 2, then F = 1   (sailh.py:388-394)
+SPART_HD double lidf_theta(int i) { return (i < 8) ? 10.0 * (i + 1) : 80.0 + 2.0 * (i - 7); }
+// litab: 5,15,...,75,81,83,...,89                                  (sailh.py:49)
+SPART_HD double lidf_litab(int i) { return (i < 8) ? 5.0 + 10.0 * i : 81.0 + 2.0 * (i - 8); }
+
+// lidf[13] = diff of the cumulative distribution (sailh.py:386-398)
+SPART_HD void leaf_angles(double a, double b, double lidf[NLINCL]) {
+  double prev = 0.0;
+  for (int i = 0; i < NLINCL; ++i) {
+    double F = (i < NLINCL - 1) ? lidf_dcum(a, b, lidf_theta(i)) : 1.0;
+    lidf[i] = F - prev;
+    prev = F;
+  }
+}
+
+// _volscatt for one leaf inclination (sailh.py:401-446)
+SPART_HD void volscatt1(double sin_tts, double cos_tts, double sin_tto, double cos_tto, double psi_rad, double sin_l,
+                        double cos_l, double& chi_s, double& chi_o, double& frho, double& ftau) {
+  double cos_psi = ::cos(psi_rad);
+  double Cs = cos_l * cos_tts, Ss = sin_l * sin_tts;
+  double Co = cos_l * cos_tto, So = sin_l * sin_tto;
+  double As = ::fmax(Ss, Cs), Ao = ::fmax(So, Co);
+  double bts = ::acos(-Cs / As), bto = ::acos(-Co / Ao);
+  chi_o = 2.0 / PI * ((bto - PI / 2) * Co + ::sin(bto) * So);
+  chi_s = 2.0 / PI * ((bts - PI / 2) * Cs + ::sin(bts) * Ss);
+  double delta1 = ::fabs(bts - bto);
+  double delta2 = PI - ::fabs(bts + bto - PI);
+  double Tot = psi_rad + delta1 + delta2;
+  double bt1 = ::fmin(psi_rad, delta1);
+  double bt3 = ::fmax(psi_rad, delta2);
+  double bt2 = Tot - bt1 - bt3;
+  double T1 = 2.0 * Cs * Co + Ss * So * cos_psi;
+  double T2 = ::sin(bt2) * (2.0 * As * Ao + Ss * So * ::cos(bt1) * ::cos(bt3));
+  double Jmin = bt2 * T1 - T2;
+  double Jplus = (PI - bt2) * T1 + T2;
+  frho = ::fmax(0.0, Jplus / (2.0 * PI * PI));
+  ftau = ::fmax(0.0, -Jmin / (2.0 * PI * PI));
+}
+
+// 16-point Gauss-Legendre on [-1,1] (positive half; symmetric)
+static constexpr double GL16_X[8] = {0.0950125098376374401853193, 0.2816035507792589132304605,
+                                     0.4580167776572273863424194, 0.6178762444026437484466718,
+                                     0.7554044083550030338951012, 0.8656312023878317438804679,
+                                     0.9445750230732325760779884, 0.9894009349916499325961542};
+static constexpr double GL16_W[8] = {0.1894506104550684962853967, 0.1826034150449235888667637,
+                                     0.1691565193950025381893121, 0.1495959888165767320815017,
+                                     0.1246289712555338720524763, 0.0951585116824927848099251,
+                                     0.0622535239386478928628438, 0.0271524594117540948517806};
+
+// Hot-spot integrals (sailh.py:115-135, 216, 219).  The reference integrates Psofunction over
+// each of the 61 layers [xl_j - dx, xl_j] with QUADPACK and uses only
+//   sum_{j<60} Pso_j * dx = int_{-1}^{0} f,   Pso_60 = (1/dx) int_{-1-dx}^{-1} f   (sic: below the canopy).
+// Both are evaluated here with 16-point Gauss-Legendre panels that halve towards x = 0, where
+// f varies on the scale 1/max(alpha, (K+k)LAI).
+struct PsoFn {
+  double A, C, alpha;
+  bool hot;  // dso == 0
+  SPART_HD double operator()(double x) const {
+    if (hot) return ::exp(A * x);  // A holds (K+k-sqrt(Kk)) LAI in this branch (:127)
+    return ::exp(A * x + C * (-::expm1(alpha * x)));  // :121-125
+  }
+};
+
+SPART_HD double gl16_panel(const PsoFn& f, double a, double b) {
+  double h = 0.5 * (b - a), c = 0.5 * (b + a), s = 0.0;
+  for (int i = 0; i < 8; ++i) s += GL16_W[i] * (f(c + h * GL16_X[i]) + f(c - h * GL16_X[i]));
+  return s * h;
+}
+
+SPART_HD void hotspot_integrals(double K, double k, double LAI, double q, double dso, double& int_canopy,
+                                double& pso2w) {
+  const double dx = 1.0 / NLAYER;
+  PsoFn f;
+  double rate;
+  if (dso != 0.0) {
+    f.hot = false;
+    f.alpha = (dso / q) * 2.0 / (k + K);
+    f.A = (K + k) * LAI;
+    f.C = ::sqrt(K * k) * LAI / f.alpha;
+    rate = ::fmax(f.alpha, f.A + ::sqrt(K * k) * LAI);
+  } else {
+    f.hot = true;
+    f.alpha = 0.0;
+    f.C = 0.0;
+    f.A = (K + k) * LAI - ::sqrt(K * k) * LAI;
+    rate = f.A;
+  }
+  // number of halvings so that rate * 2^-m <= 4 (NaN / inf rates fall through with m = 0 / 40)
+  int m = 0;
+  double hw = 1.0;
+  while (rate * hw > 4.0 && m < 40) {
+    hw *= 0.5;
+    ++m;
+  }
+  double tot = 0.0, lo = -1.0;
+  for (int i = 0; i < m; ++i) {
+    tot += gl16_panel(f, lo, 0.5 * lo);
+    lo *= 0.5;
+  }
+  tot += gl16_panel(f, lo, 0.0);
+  int_canopy = tot;
+  pso2w = gl16_panel(f, -1.0 - dx, -1.0) / dx;
+}
+
+// ------------------------------------------------------------------------------------------
+// The prelude: 27 parameters -> band-kernel constants (T) + atmosphere scalars (double)
+enum PreludeMask { PRE_LEAF = 1, PRE_SOIL = 2, PRE_CANOPY = 4, PRE_ATM = 8, PRE_ALL = 15 };
+
+template <typename T>
+SPART_HD void sample_prelude(const double* p /*[27]*/, double rho_th, double tau_th, int mask, T* cst /*[NCONST]*/,
+                             double* atm /*[NATM]*/, double* lidf_out /*[13]*/) {
+  SPART_NO_CONTRACT
+  const double d2r = PI / 180.0;
+  for (int i = 0; i < NCONST; ++i) cst[i] = T(0);
+  for (int i = 0; i < NATM; ++i) atm[i] = 0.0;
+  for (int i = 0; i < NLINCL; ++i) lidf_out[i] = 0.0;
+  if (mask & PRE_LEAF) {
+  // ---- leaf (prospect_5d.py:135-155, 170-179)
+  double Cab = p[0], Cdm = p[1], Cw = p[2], Cs = p[3], Cca = p[4], Cant = p[5], N = p[6], PROT = p[7], CBC = p[8];
+  if ((PROT > 0.0 || CBC > 0.0) && Cdm > 0.0) Cdm = 0.0;  // PROSPECT-PRO rule (:148-155)
+  double iN = 1.0 / N;
+  cst[C_CAB] = T(Cab * iN);
+  cst[C_CCA] = T(Cca * iN);
+  cst[C_CDM] = T(Cdm * iN);
+  cst[C_CW] = T(Cw * iN);
+  cst[C_CS] = T(Cs * iN);
+  cst[C_CANT] = T(Cant * iN);
+  cst[C_CBC] = T(CBC * iN);
+  cst[C_PROT] = T(PROT * iN);
+  cst[C_NM1] = T(N - 1.0);
+  cst[C_RHO_TH] = T(rho_th);
+  cst[C_TAU_TH] = T(tau_th);
+  }
+  if (mask & PRE_SOIL) {
+  // ---- soil (bsm.py:49-52, 99-103, 121)
+  double Bs = p[9], lat = p[10], lon = p[11], SMp = p[12], SMC = p[13], film = p[14];
+  cst[C_F1] = T(Bs * ::sin(lat * d2r));
+  cst[C_F2] = T(Bs * ::cos(lat * d2r) * ::sin(lon * d2r));
+  cst[C_F3] = T(Bs * ::cos(lat * d2r) * ::cos(lon * d2r));
+  double mu = (SMp - 5.0) / SMC;
+  bool wet = mu > 0.0;
+  cst[C_WET] = T(wet ? 1.0 : 0.0);
+  {
+    double e = wet ? ::exp(-mu) : 1.0, pw = 1.0, fact = 1.0;
+    for (int k = 0; k < 7; ++k) {  // poisson.pmf(k, mu) = e^-mu mu^k / k!
+      if (k > 0) {
+        pw *= mu;
+        fact *= k;
+      }
+      cst[C_FM0 + k] = T(wet ? e * pw / fact : (k == 0 ? 1.0 : 0.0));
+    }
+  }
+  cst[C_FILM2] = T(2.0 * film);
+  }
+  double tts = p[19], tto = p[20], rel = p[21];
+  if (mask & PRE_CANOPY) {
+  // ---- canopy geometry (sailh.py:46-105)
+  double LAI = p[15], LIDFa = p[16], LIDFb = p[17], q = p[18];
+  double psi = ::fabs(rel - 360.0 * ::rint(rel / 360.0));  // :65 (Python round = half-to-even = rint)
+  double psi_rad = psi * d2r;
+  double sin_tts = ::sin(tts * d2r), cos_tts = ::cos(tts * d2r), tan_tts = ::tan(tts * d2r);
+  double sin_tto = ::sin(tto * d2r), cos_tto = ::cos(tto * d2r), tan_tto = ::tan(tto * d2r);
+  double dso = ::sqrt(tan_tts * tan_tts + tan_tto * tan_tto - 2.0 * tan_tts * tan_tto * ::cos(psi_rad));  // :78
+  double ks = 0, ko = 0, bf = 0, sob = 0, sof = 0, Fprev = 0;
+  for (int i = 0; i < NLINCL; ++i) {
+    double F = (i < NLINCL - 1) ? lidf_dcum(LIDFa, LIDFb, lidf_theta(i)) : 1.0;
+    double li = F - Fprev;
+    Fprev = F;
+    lidf_out[i] = li;
+    double tl = lidf_litab(i) * d2r;
+    double sl = ::sin(tl), cl = ::cos(tl);
+    double chi_s, chi_o, frho, ftau;
+    volscatt1(sin_tts, cos_tts, sin_tto, cos_tto, psi_rad, sl, cl, chi_s, chi_o, frho, ftau);  // :81-83
+    ks += chi_s / cos_tts * li;                                                               // :85, 93
+    ko += chi_o / cos_tto * li;                                                               // :86, 94
+    bf += cl * cl * li;                                                                       // :90, 95
+    sob += frho * PI / (cos_tts * cos_tto) * li;                                              // :88, 96
+    sof += ftau * PI / (cos_tts * cos_tto) * li;                                              // :89, 97
+  }
+  cst[C_SDB] = T(0.5 * (ks + bf));  // :100-105
+  cst[C_SDF] = T(0.5 * (ks - bf));
+  cst[C_DDB] = T(0.5 * (1.0 + bf));
+  cst[C_DDF] = T(0.5 * (1.0 - bf));
+  cst[C_DOB] = T(0.5 * (ko + bf));
+  cst[C_DOF] = T(0.5 * (ko - bf));
+  cst[C_SOB] = T(sob);
+  cst[C_SOF] = T(sof);
+  cst[C_BF] = T(bf);
+  cst[C_KS] = T(ks);
+  cst[C_KO] = T(ko);
+  cst[C_LAI] = T(LAI);
+  double tss = ::exp(-ks * LAI), too = ::exp(-ko * LAI);  // :200-201
+  cst[C_TSS] = T(tss);
+  cst[C_TOO] = T(too);
+  cst[C_Z] = T((1.0 - tss * too) / (ko + ks));             // :203
+  double ic, p2w;
+  hotspot_integrals(ko, ks, LAI, q, dso, ic, p2w);
+  cst[C_HOT] = T(ic * LAI);   // sum(Pso[0:60]) * iLAI  (:216)
+  cst[C_PSO2W] = T(p2w);      // Pso[60]               (:219)
+  }
+  if (mask & PRE_ATM) {
+  // ---- atmosphere scalars (smac.py:94-102, 128-138) + ET factor (SPART.py:345-353)
+  double psi_s = p[21];  // SMAC uses rel_angle unfolded (smac.py:38)
+  double Pa = p[25];
+  const double cdr = PI / 180.0, crd = 180.0 / PI;
+  double us = ::cos(tts * cdr), uv = ::cos(tto * cdr);
+  double cksi = -((us * uv) + (::sqrt(1.0 - us * us) * ::sqrt(1.0 - uv * uv) * ::cos(psi_s * crd)));  // sic (:130)
+  if (cksi < -1.0) cksi = -1.0;                                                                        // :134-135
+  atm[A_US] = us;
+  atm[A_UV] = uv;
+  atm[A_M] = 1.0 / us + 1.0 / uv;
+  atm[A_PEQ] = Pa / 1013.25;
+  atm[A_PA] = Pa;
+  atm[A_AOT] = p[22];
+  atm[A_UO3] = p[23];
+  atm[A_UH2O] = p[24];
+  atm[A_CKSI] = cksi;
+  atm[A_KSID] = crd * ::acos(cksi);
+  double b = 2.0 * PI * p[26] / 365.0;
+  double corr = 1.00011 + 0.034221 * ::cos(b) + 0.00128 * ::sin(b) + 0.000719 * ::cos(2.0 * b) +
+                0.000077 * ::sin(2.0 * b);
+  atm[A_LAF] = corr * ::cos(tts * PI / 180.0) / PI;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// SMAC for one (sample, sensor band)                                     (smac.py:94-211)
+// coef points at this band's 48 coefficients with stride `cs` between rows.
+struct SmacOut {
+  double Ta_s, Ta_o, Tg, Ra_dd, Ra_so, Ta_ss, Ta_sd, Ta_oo, Ta_do;
+};
+
+enum CoefRow {
+  K_AH2O = 0, K_NH2O, K_AO3, K_NO3, K_AO2, K_NO2, K_PO2, K_ACO2, K_NCO2, K_PCO2, K_ACH4, K_NCH4, K_PCH4,
+  K_ANO2, K_NNO2, K_PNO2, K_ACO, K_NCO, K_PCO, K_A0S, K_A1S, K_A2S, K_A3S, K_A0T, K_A1T, K_A2T, K_A3T,
+  K_TAUR, K_A0TAUP, K_A1TAUP, K_WO, K_GC, K_A0P, K_A1P, K_A2P, K_A3P, K_A4P, K_REST1, K_REST2, K_REST3,
+  K_REST4, K_RESR1, K_RESR2, K_RESR3, K_RESA1, K_RESA2, K_RESA3, K_RESA4
+};
+
+SPART_HD SmacOut smac_band(const double* atm, const double* coef, int cs) {
+  auto C = [&](int r) { return coef[(size_t)r * cs]; };
+  double us = atm[A_US], uv = atm[A_UV], m = atm[A_M], Peq = atm[A_PEQ], Pa = atm[A_PA];
+  double taup550 = atm[A_AOT], uo3 = atm[A_UO3], uh2o = atm[A_UH2O], cksi = atm[A_CKSI], ksiD = atm[A_KSID];
+  double taup = C(K_A0TAUP) + C(K_A1TAUP) * taup550;  // :103
+  double uo2 = ::pow(Peq, C(K_PO2));                   // :105-109
+  double uco2 = ::pow(Peq, C(K_PCO2));
+  double uch4 = ::pow(Peq, C(K_PCH4));
+  double uno2 = ::pow(Peq, C(K_PNO2));
+  double uco = ::pow(Peq, C(K_PCO));
+  double to3 = ::exp(C(K_AO3) * ::pow(uo3 * m, C(K_NO3)));  // :111-117
+  double th2o = ::exp(C(K_AH2O) * ::pow(uh2o * m, C(K_NH2O)));
+  double to2 = ::exp(C(K_AO2) * ::pow(uo2 * m, C(K_NO2)));
+  double tco2 = ::exp(C(K_ACO2) * ::pow(uco2 * m, C(K_NCO2)));
+  double tch4 = ::exp(C(K_ACH4) * ::pow(uch4 * m, C(K_NCH4)));
+  double tno2 = ::exp(C(K_ANO2) * ::pow(uno2 * m, C(K_NNO2)));
+  double tco = ::exp(C(K_ACO) * ::pow(uco * m, C(K_NCO)));
+  SmacOut o;
+  o.Tg = th2o * to3 * to2 * tco2 * tch4 * tco * tno2;  // :119
+  o.Ra_dd = C(K_A0S) * Peq + C(K_A3S) + C(K_A1S) * taup550 + C(K_A2S) * taup550 * taup550;  // :122
+  o.Ta_s = C(K_A0T) + C(K_A1T) * taup550 / us + (C(K_A2T) * Peq + C(K_A3T)) / (1.0 + us);  // :125
+  o.Ta_o = C(K_A0T) + C(K_A1T) * taup550 / uv + (C(K_A2T) * Peq + C(K_A3T)) / (1.0 + uv);  // :126
+  double taur = C(K_TAUR);
+  double ray_phase = 0.7190443 * (1.0 + (cksi * cksi)) + 0.0412742;  // :141
+  double ray_ref = (taur * ray_phase) / (4.0 * us * uv);             // :142
+  ray_ref = ray_ref * Pa / 1013.25;                                  // :143
+  double taurz = taur * Peq;                                         // :144
+  double aer_phase = C(K_A0P) + C(K_A1P) * ksiD + C(K_A2P) * ksiD * ksiD + C(K_A3P) * ksiD * ksiD * ksiD +
+                     C(K_A4P) * (ksiD * ksiD) * (ksiD * ksiD);  // :146-148
+  double wo = C(K_WO), gc = C(K_GC);
+  double ak2 = (1.0 - wo) * (3.0 - wo * 3.0 * gc);  // :149-150
+  double ak = ::sqrt(ak2);
+  double e = -3.0 * us * us * wo / (4.0 * (1.0 - ak2 * us * us));  // :153-157
+  double f = -(1.0 - wo) * 3.0 * gc * us * us * wo / (4.0 * (1.0 - ak2 * us * us));
+  double dp = e / (3.0 * us) + us * f;
+  double d = e + f;
+  double b = 2.0 * ak / (3.0 - wo * 3.0 * gc);
+  double eak = ::exp(ak * taup), emak = ::exp(-ak * taup);
+  double delta = eak * (1.0 + b) * (1.0 + b) - emak * (1.0 - b) * (1.0 - b);  // :158
+  double ww = wo / 4.0;
+  double ss = us / (1.0 - ak2 * us * us);
+  double q1 = 2.0 + 3.0 * us + (1.0 - wo) * 3.0 * gc * us * (1.0 + 2.0 * us);
+  double q2 = 2.0 - 3.0 * us - (1.0 - wo) * 3.0 * gc * us * (1.0 - 2.0 * us);
+  double q3 = q2 * ::exp(-taup / us);
+  double c1 = ((ww * ss) / delta) * (q1 * eak * (1.0 + b) + q3 * (1.0 - b));   // :164
+  double c2 = -((ww * ss) / delta) * (q1 * emak * (1.0 - b) + q3 * (1.0 + b));  // :165
+  double cp1 = c1 * ak / (3.0 - wo * 3.0 * gc);
+  double cp2 = -c2 * ak / (3.0 - wo * 3.0 * gc);
+  double z = d - wo * 3.0 * gc * uv * dp + wo * aer_phase / 4.0;  // :168-173
+  double x = c1 - wo * 3.0 * gc * uv * cp1;
+  double y = c2 - wo * 3.0 * gc * uv * cp2;
+  double aa1 = uv / (1.0 + ak * uv);
+  double aa2 = uv / (1.0 - ak * uv);
+  double aa3 = us * uv / (us + uv);
+  double aer_ref1 = x * aa1 * (1.0 - ::exp(-taup / aa1));  // :175-179
+  double aer_ref2 = y * aa2 * (1.0 - ::exp(-taup / aa2));
+  double aer_ref3 = z * aa3 * (1.0 - ::exp(-taup / aa3));
+  double aer_ref = (aer_ref1 + aer_ref2 + aer_ref3) / (us * uv);
+  double rr = taur * ray_phase / (us * uv);
+  double Res_ray = C(K_RESR1) + C(K_RESR2) * rr + C(K_RESR3) * (rr * rr);  // :182-186
+  double ta = taup * m * cksi;
+  double Res_aer = (C(K_RESA1) + C(K_RESA2) * ta + C(K_RESA3) * (ta * ta)) + C(K_RESA4) * (ta * ta * ta);  // :189-191
+  double tautot = taup + taurz;  // :194
+  double tt = tautot * m * cksi;
+  double Res_6s = (C(K_REST1) + C(K_REST2) * tt + C(K_REST3) * (tt * tt)) + C(K_REST4) * (tt * tt * tt);  // :196-198
+  o.Ra_so = ray_ref - Res_ray + aer_ref - Res_aer + Res_6s;  // :201
+  o.Ta_ss = ::exp(-tautot / us);                             // :204-207
+  o.Ta_oo = ::exp(-tautot / uv);
+  o.Ta_sd = o.Ta_s - o.Ta_ss;
+  o.Ta_do = o.Ta_o - o.Ta_oo;
+  return o;
+}
+
+// TOC -> TOA (SPART.py:243-252)
+SPART_HD void toc_to_toa(const SmacOut& a, double rv_so, double rv_do, double rv_dd, double rv_sd, double La,
+                         double& R_TOC, double& R_TOA, double& L_TOA) {
+  double rtoa0 = a.Ra_so + a.Ta_ss * rv_so * a.Ta_oo;
+  double rtoa1 = (a.Ta_sd * rv_do + a.Ta_ss * rv_sd * a.Ra_dd * rv_do) * a.Ta_oo / (1.0 - rv_dd * a.Ra_dd);
+  double rtoa2 = (a.Ta_ss * rv_sd + a.Ta_sd * rv_dd) * a.Ta_do / (1.0 - rv_dd * a.Ra_dd);
+  R_TOC = (a.Ta_ss * rv_so + a.Ta_sd * rv_do) / (a.Ta_ss + a.Ta_sd);
+  R_TOA = a.Tg * (rtoa0 + rtoa1 + rtoa2);
+  L_TOA = La * R_TOA;
+}
+
+}  // namespace spart

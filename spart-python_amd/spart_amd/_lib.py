@@ -1,0 +1,77 @@
+"""ctypes binding of libspart_hip.so (include/spart_hip.h).  There is no CPU path: if the
+library or a GPU is missing every compute entry point raises."""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.normpath(os.path.join(HERE, "..", "libspart_hip.so"))
+
+SPART_F32, SPART_F64 = 0, 1
+NPARAM, NCOEF, NWL, NWLS, NLINCL = 27, 48, 2001, 2162, 13
+
+c_dp = ctypes.POINTER(ctypes.c_double)
+vp = ctypes.c_void_p
+
+
+class SpartTables(ctypes.Structure):
+    _fields_ = [(n, c_dp) for n in ("nr", "Kab", "Kca", "Kdm", "Kw", "Ks", "Kant", "cbc", "prot", "GSV", "nw", "Ea")] + [
+        ("nb", ctypes.c_int32), ("wl_smac", c_dp), ("coef", c_dp), ("nsrf", ctypes.c_int32), ("wl_srf", c_dp),
+        ("p_srf", c_dp)]
+
+
+class SpartMaterialize(ctypes.Structure):
+    _fields_ = [(n, vp) for n in ("leaf_refl", "leaf_tran", "leaf_kchl", "soil_refl", "soil_refl_dry", "rso", "rdo",
+                                  "rsd", "rdd", "rsoil", "La")]
+
+
+# name -> (restype, argtypes): every symbol include/spart_hip.h declares
+SIGNATURES = {
+    "spart_ctx_create": (ctypes.c_int, [ctypes.POINTER(vp), ctypes.c_int, ctypes.POINTER(SpartTables)]),
+    "spart_ctx_destroy": (ctypes.c_int, [vp]),
+    "spart_last_error": (ctypes.c_char_p, [vp]),
+    "spart_ctx_nb": (ctypes.c_int, [vp]),
+    "spart_ctx_econv": (ctypes.c_int, [vp, c_dp]),
+    "spart_workspace_bytes": (ctypes.c_size_t, [vp, ctypes.c_int, ctypes.c_int64]),
+    "spart_prospect_batch": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int64, ctypes.POINTER(vp), vp, vp, vp, vp,
+                                            ctypes.c_size_t, vp]),
+    "spart_bsm_batch": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int64, ctypes.POINTER(vp), vp, vp, vp, vp,
+                                       ctypes.c_size_t, vp]),
+    "spart_lidf_batch": (ctypes.c_int, [vp, ctypes.c_int64, vp, vp, vp, vp]),
+    "spart_sailh_batch": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int64, vp, vp, vp, ctypes.POINTER(vp),
+                                         ctypes.POINTER(vp), ctypes.POINTER(vp), vp, ctypes.c_size_t, vp]),
+    "spart_smac_batch": (ctypes.c_int, [vp, ctypes.c_int64, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp),
+                                        vp, ctypes.c_size_t, vp]),
+    "spart_run_batch": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int64, ctypes.POINTER(vp), vp, vp, vp, vp, vp,
+                                       ctypes.POINTER(SpartMaterialize), vp, ctypes.c_size_t, vp]),
+    "spart_profile_enable": (ctypes.c_int, [vp, ctypes.c_int]),
+    "spart_profile_read": (ctypes.c_int, [vp, c_dp, ctypes.POINTER(ctypes.c_int)]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the library (torch is imported first so that its HIP runtime, soname
+    libamdhip64.so.7, is the one both sides use)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401
+
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python spart-python_amd/build.py` "
+            "(hipcc, gfx950). spart_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(lib, ctx, rc):
+    if rc != 0:
+        msg = lib.spart_last_error(ctx)
+        raise RuntimeError(f"libspart_hip error {rc}: {msg.decode() if msg else '?'}")

@@ -1,0 +1,424 @@
+"""The reference's public surface (src/SPART/__init__.py:1-5) on top of the HIP engine.
+
+Same constructor names, positional order and defaults as wirrell/SPART-python; every field
+accepts a scalar (reference behaviour) or a length-B array (batched evaluation).  Scalar
+calls return objects shaped like the reference's ((n,1) column vectors, a pandas DataFrame
+from SPART.run()); batched calls return (B, n) arrays.
+"""
+import warnings
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import engine as _engine
+from . import tables as _tables
+from .tables import load_ET_parameters, load_optical_parameters, load_sensor_info  # noqa: F401 (re-exported)
+
+
+def _is_scalar(*vals):
+    return all(np.ndim(v) == 0 for v in vals)
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _colvec(t, scalar):
+    """(B,n) device tensor -> reference layout: (n,1) for a scalar call, (B,n) otherwise."""
+    a = _np(t)
+    return a[0][:, None].copy() if scalar else a
+
+
+# ------------------------------------------------------------------------------- leaf
+@dataclass
+class LeafBiology:
+    """prospect_5d.py:19-83 -- positional order Cab, Cdm, Cw, Cs, Cca, Cant, N, then PROT, CBC,
+    rho_thermal, tau_thermal."""
+    Cab: float
+    Cdm: float
+    Cw: float
+    Cs: float
+    Cca: float
+    Cant: float
+    N: float
+    PROT: float = 0.0
+    CBC: float = 0.0
+    rho_thermal: float = 0.01
+    tau_thermal: float = 0.01
+
+    def columns(self):
+        return [self.Cab, self.Cdm, self.Cw, self.Cs, self.Cca, self.Cant, self.N, self.PROT, self.CBC]
+
+
+@dataclass
+class LeafOptics:
+    """prospect_5d.py:86-114"""
+    refl: np.ndarray
+    tran: np.ndarray
+    kChlrel: np.ndarray
+
+
+_PRO_WARNING = ("WARNING: When setting PROT and/or CBC > 0. we\n"
+                "assume that PROSPECT-PRO was called. Cdm will be\n"
+                "therefore set to zero (Cdm = PROT + CBC)")
+
+
+def _pro_warning(leafbio):
+    prot, cbc, cdm = (np.asarray(x, dtype=np.float64) for x in (leafbio.PROT, leafbio.CBC, leafbio.Cdm))
+    if np.any(((prot > 0.0) | (cbc > 0.0)) & (cdm > 0)):
+        print(_PRO_WARNING)          # prospect_5d.py:148-155 (once per call, not per sample)
+
+
+def PROSPECT_5D(leafbio, optical_params=None, dtype="float64", device=None):
+    """prospect_5d.py:117-246.  ``optical_params`` is accepted for signature compatibility; the
+    engine holds its own device copy of the same tables."""
+    _pro_warning(leafbio)
+    eng = _engine.get_engine(None, device)
+    refl, tran, kchl = eng.prospect(leafbio.columns(), dtype)
+    sc = _is_scalar(*leafbio.columns())
+    return LeafOptics(_colvec(refl, sc), _colvec(tran, sc), _colvec(kchl, sc))
+
+
+# ------------------------------------------------------------------------------- soil
+class SoilOptics:
+    """bsm.py:131-152"""
+
+    def __init__(self, refl, refl_dry):
+        self.refl = refl
+        self.refl_dry = refl_dry
+
+
+class SoilParameters:
+    """bsm.py:229-287"""
+
+    def __init__(self, B, lat, lon, SMp, SMC=None, film=None):
+        self.B = B
+        self.lat = lat
+        self.lon = lon
+        self.SMp = SMp
+        if SMC is None:
+            warnings.warn("BSM soil model: SMC not supplied, set to default of 25 %")
+            self.SMC = 25
+        else:
+            self.SMC = SMC
+        if film is None:
+            warnings.warn("BSM soil model: water film optical thickness not supplied, set to default of 0.0150 cm")
+            self.film = 0.0150
+        else:
+            self.film = film
+        self.rdry_set = False
+
+    def columns(self):
+        return [self.B, self.lat, self.lon, self.SMp, self.SMC, self.film]
+
+
+class SoilParametersFromFile:
+    """bsm.py:155-226 with the dry spectrum passed as an array ((2001,), (2001,1) or (B,2001)).
+    Parsing JPL spectral-library text files is host-side I/O outside the hot path."""
+
+    def __init__(self, soil_file, SMp, SMC=None, film=None):
+        if SMC is None:
+            warnings.warn("BSM soil model: SMC not supplied, set to default of 25 %")
+            self.SMC = 25
+        else:
+            self.SMC = SMC
+        if film is None:
+            warnings.warn("BSM soil model: water film optical thickness not supplied,")
+            warnings.warn("\t set to default of 0.0150 cm")
+            self.film = 0.0150
+        else:
+            self.film = film
+        if not isinstance(soil_file, np.ndarray):
+            raise NotImplementedError("pass the dry soil reflectance as a numpy array (400-2400 nm, 1 nm)")
+        self.rdry = soil_file
+        self.SMp = SMp
+        self.rdry_set = True
+
+    def columns(self):
+        return [None, None, None, self.SMp, self.SMC, self.film]
+
+
+def BSM(soilpar, optical_params=None, dtype="float64", device=None):
+    """bsm.py:17-59"""
+    eng = _engine.get_engine(None, device)
+    rdry = soilpar.rdry if soilpar.rdry_set else None
+    refl, dry = eng.bsm(soilpar.columns(), dtype, rdry=rdry)
+    sc = _is_scalar(*[c for c in soilpar.columns() if c is not None]) and (rdry is None or np.size(rdry) == 2001)
+    return SoilOptics(_colvec(refl, sc), _colvec(dry, sc))
+
+
+# ------------------------------------------------------------------------------- canopy
+class CanopyReflectances:
+    """sailh.py:240-272"""
+
+    def __init__(self, rso, rdo, rsd, rdd):
+        self.rso = rso
+        self.rdo = rdo
+        self.rsd = rsd
+        self.rdd = rdd
+
+
+class Angles:
+    """sailh.py:275-301"""
+
+    def __init__(self, sol_angle, obs_angle, rel_angle):
+        self.sol_angle = sol_angle
+        self.obs_angle = obs_angle
+        self.rel_angle = rel_angle
+
+    def columns(self):
+        return [self.sol_angle, self.obs_angle, self.rel_angle]
+
+
+def calculate_leafangles(LIDFa, LIDFb, device=None):
+    """sailh.py:351-398: (13,1) for scalars, (B,13) for arrays."""
+    eng = _engine.get_engine(None, device)
+    return _colvec(eng.lidf(LIDFa, LIDFb), _is_scalar(LIDFa, LIDFb))
+
+
+class CanopyStructure:
+    """sailh.py:304-348.  ``lidf`` is evaluated on first access (the reference computes it in
+    the constructor); the full-chain kernel derives it itself from LIDFa / LIDFb."""
+
+    def __init__(self, LAI, LIDFa, LIDFb, q):
+        self.LAI = LAI
+        self.LIDFa = LIDFa
+        self.LIDFb = LIDFb
+        self.q = q
+        self.nlayers = 60
+        self.nlincl = 13
+        self.nlazi = 36
+        self._lidf = None
+
+    @property
+    def lidf(self):
+        if self._lidf is None:
+            self._lidf = calculate_leafangles(self.LIDFa, self.LIDFb)
+        return self._lidf
+
+    def columns(self):
+        return [self.LAI, self.LIDFa, self.LIDFb, self.q]
+
+
+def SAILH(soil, leafopt, canopy, angles, dtype="float64", device=None):
+    """sailh.py:14-237"""
+    refl = np.asarray(leafopt.refl)
+    nband = refl.shape[0] if (refl.ndim == 1 or refl.shape[-1] == 1) else refl.shape[-1]
+    if nband != 2162:
+        raise RuntimeError(
+            "Parameter leafopt.refl must be of len 2162"
+            " i.e. include thermal specturm. \n This error"
+            " usually occurs if you are feeding the prospect_5d"
+            " output directly into the SAILH model with adding"
+            "\n the neccessary thermal wavelengths."
+        )
+    eng = _engine.get_engine(None, device)
+    out = eng.sailh(leafopt.refl, leafopt.tran, soil.refl, canopy.columns(), angles.columns(), dtype)
+    sc = out[0].shape[0] == 1 and _is_scalar(*canopy.columns(), *angles.columns())
+    return CanopyReflectances(*[_colvec(o, sc) for o in out])
+
+
+# ------------------------------------------------------------------------------- atmosphere
+class AtmosphericOptics:
+    """smac.py:216-272"""
+
+    def __init__(self, Ta_s, Ta_o, Tg, Ra_dd, Ra_so, Ta_ss, Ta_sd, Ta_oo, Ta_do):
+        self.Ta_s = Ta_s
+        self.Ta_o = Ta_o
+        self.Tg = Tg
+        self.Ra_dd = Ra_dd
+        self.Ra_so = Ra_so
+        self.Ta_ss = Ta_ss
+        self.Ta_sd = Ta_sd
+        self.Ta_oo = Ta_oo
+        self.Ta_do = Ta_do
+
+
+def _calculate_pressure_from_altitude(alt_m, temp_k):
+    """smac.py:320-330"""
+    g, M, R0, Pa0 = 9.80665, 0.02896968, 8.314462618, 1013.25
+    return Pa0 * np.exp(-(g * np.asarray(alt_m, dtype=np.float64) * M / (np.asarray(temp_k, dtype=np.float64) * R0)))
+
+
+class AtmosphericProperties:
+    """smac.py:275-317"""
+
+    def __init__(self, aot550, uo3, uh2o, Pa=None, alt_m=None, temp_k=None):
+        self.aot550 = aot550
+        self.uo3 = uo3
+        self.uh2o = uh2o
+        if Pa is None:
+            if alt_m is not None and temp_k is not None:
+                self.Pa = _calculate_pressure_from_altitude(alt_m, temp_k)
+            else:
+                self.Pa = 1013.25
+        else:
+            self.Pa = Pa
+
+    def columns(self):
+        return [self.aot550, self.uo3, self.uh2o, self.Pa]
+
+
+def SMAC(angles, atm, coefs, device=None):
+    """smac.py:14-213.  ``coefs`` may be a sensor name or the SMAC_coef dict of load_sensor_info()."""
+    if isinstance(coefs, str):
+        eng = _engine.get_engine(coefs, device)
+    else:
+        eng = _engine_for_coefs(coefs, device)
+    out = eng.smac(angles.columns(), atm.columns())
+    # reference layout is (1, nb) per field for a scalar call
+    return AtmosphericOptics(*[_np(out[f]) for f in _engine.SMAC_FIELDS])
+
+
+def _engine_for_coefs(coefs, device):
+    key = id(coefs)
+    cache = _engine_for_coefs.__dict__.setdefault("cache", {})
+    if key not in cache:
+        nb = np.asarray(coefs["taur"]).size
+        si = {"wl_smac": np.full((nb, 1), 500.0), "band_id_smac": [""] * nb, "SMAC_coef": coefs,
+              "wl_srf_smac": np.full((1, nb), 500.0), "p_srf_smac": np.ones((1, nb))}
+        import torch
+        cache[key] = _engine.Engine(None, torch.cuda.current_device() if device is None else device, sensor_info=si)
+    return cache[key]
+
+
+# ------------------------------------------------------------------------------- orchestration
+class SpectralBands:
+    """SPART.py:272-315"""
+
+    def __init__(self):
+        self.wlP = np.arange(400, 2401, 1)
+        self.wlE = np.arange(400, 751, 1)
+        self.WlF = np.arange(640, 851, 1)
+        self.wlO = np.arange(400, 2401, 1)
+        self.wlT = np.concatenate([np.arange(2500, 15001, 100), np.arange(16000, 50001, 1000)])
+        self.wlS = np.concatenate([self.wlO, self.wlT])
+        self.wlPAR = np.arange(400, 701, 1)
+        self.nwlP = len(self.wlP)
+        self.nwlT = len(self.wlT)
+        self.IwlP = np.arange(0, self.nwlP, 1)
+        self.IwlT = np.arange(self.nwlP, self.nwlP + self.nwlT, 1)
+
+
+def set_soil_refl_trans_assumptions(soilopt, spectral):
+    """SPART.py:427-442: pad the soil spectrum with its 2400 nm value (mutates and returns soilopt)."""
+    r = np.asarray(soilopt.refl)
+    if r.ndim == 2 and r.shape[1] == 1:
+        soilopt.refl = np.concatenate([r, np.repeat(r[spectral.nwlP - 1:spectral.nwlP], spectral.nwlT, axis=0)], axis=0)
+    else:
+        r = np.atleast_2d(r)
+        soilopt.refl = np.concatenate([r, np.repeat(r[:, spectral.nwlP - 1:spectral.nwlP], spectral.nwlT, axis=1)], axis=1)
+    return soilopt
+
+
+def set_leaf_refl_trans_assumptions(leafopt, leafbio, spectral):
+    """SPART.py:445-470: pad leaf refl/tran with rho_thermal / tau_thermal (mutates and returns leafopt)."""
+    def pad(x, v):
+        x = np.asarray(x)
+        if x.ndim == 2 and x.shape[1] == 1:
+            return np.concatenate([x, np.full((spectral.nwlT, 1), float(np.asarray(v).reshape(-1)[0]))], axis=0)
+        x = np.atleast_2d(x)
+        vv = np.broadcast_to(np.asarray(v, dtype=np.float64).reshape(-1, 1), (x.shape[0], 1))
+        return np.concatenate([x, np.repeat(vv, spectral.nwlT, axis=1)], axis=1)
+    leafopt.refl = pad(leafopt.refl, leafbio.rho_thermal)
+    leafopt.tran = pad(leafopt.tran, leafbio.tau_thermal)
+    return leafopt
+
+
+def calculate_ET_radiance(Ea, DOY, tts):
+    """SPART.py:318-355 (host numpy; the batched path applies the same factor inside the kernels)."""
+    b = 2 * np.pi * DOY / 365
+    corr = 1.00011 + 0.034221 * np.cos(b) + 0.00128 * np.sin(b) + 0.000719 * np.cos(2 * b) + 0.000077 * np.sin(2 * b)
+    return Ea * corr * np.cos(tts * np.pi / 180) / np.pi
+
+
+def calculate_spectral_convolution(wl_hi, radiation_spectra, sensorinfo):
+    """SPART.py:358-396 for the 400..2400 nm 1 nm grid: nearest-wavelength lookup (ties to the lower
+    wavelength, NaN -> first entry, exactly what the reference's argmin does) and SRF-weighted mean."""
+    wl_hi = np.asarray(wl_hi, dtype=np.float64).reshape(-1)
+    v = np.asarray(sensorinfo["wl_srf_smac"], dtype=np.float64)
+    idx = np.ceil(v - 0.5) - wl_hi[0]
+    idx = np.clip(np.where(np.isnan(v), 0, idx), 0, wl_hi.size - 1).astype(np.int64)
+    rad = np.asarray(radiation_spectra, dtype=np.float64).reshape(-1)[idx]
+    p = sensorinfo["p_srf_smac"]
+    return np.sum(rad * p, axis=0) / np.sum(p, axis=0)
+
+
+class BatchResult(dict):
+    """Result of a batched SPART.run(): arrays (B, nb) keyed 'R_TOC', 'R_TOA', 'L_TOA' (+ optional
+    materialised fields), with the band table attached."""
+
+    def __init__(self, data, wl, bands):
+        super().__init__(data)
+        self.wavelengths = wl
+        self.bands = bands
+
+    def to_dataframe(self):
+        import pandas as pd
+        B, nb = self["R_TOC"].shape
+        idx = pd.MultiIndex.from_product([range(B), self.wavelengths], names=["sample", "wavelength"])
+        cols = {"Band": np.tile(np.asarray(self.bands, dtype=object), B)}
+        for k in ("L_TOA", "R_TOA", "R_TOC"):
+            cols[k] = np.asarray(self[k]).reshape(-1)
+        if "rsoil" in self:
+            cols["rsoil"] = np.asarray(self["rsoil"]).reshape(-1)
+        return pd.DataFrame(cols, index=idx)
+
+
+class SPART:
+    """SPART.py:35-269.  Stateless per call: every run() evaluates all stages for the current
+    parameter objects, which equals what a FRESH reference object returns (the reference's
+    per-object change tracker is not reproduced)."""
+
+    def __init__(self, soilpar, leafbio, canopy, atm, angles, sensor, DOY, dtype="float64", device=None):
+        self.soilpar = soilpar
+        self.leafbio = leafbio
+        self.canopy = canopy
+        self.atm = atm
+        self.angles = angles
+        self.sensor = sensor
+        self.DOY = DOY
+        self.dtype = dtype
+        self.device = device
+        self.spectral = SpectralBands()
+        self.sensorinfo = load_sensor_info(sensor)       # FileNotFoundError for unknown sensors (SPART.py:421-423)
+
+    def _columns(self):
+        if getattr(self.soilpar, "rdry_set", False):
+            raise NotImplementedError("SPART.run with user dry-soil spectra: use BSM()/SAILH() stage by stage")
+        return (self.leafbio.columns() + self.soilpar.columns() + self.canopy.columns() + self.angles.columns()
+                + self.atm.columns() + [self.DOY])
+
+    def run(self, debug=False, materialize=False):
+        """Returns the reference's DataFrame (columns Band, L_TOA, R_TOA, R_TOC indexed by band
+        centre) for scalar parameters, a BatchResult of (B, nb) arrays otherwise."""
+        import pandas as pd
+        _pro_warning(self.leafbio)
+        eng = _engine.get_engine(self.sensor, self.device)
+        cols = self._columns()
+        fields = ["La"]
+        if debug:
+            fields.append("rsoil")
+        if materialize:
+            fields += ["leaf_refl", "leaf_tran", "leaf_kchl", "soil_refl", "soil_refl_dry", "rso", "rdo", "rsd", "rdd"]
+        res = eng.run(cols, self.dtype, rho_thermal=self.leafbio.rho_thermal, tau_thermal=self.leafbio.tau_thermal,
+                      materialize=fields)
+        out = {k: _np(v) for k, v in res.items()}
+        scalar = _is_scalar(*cols) and out["R_TOC"].shape[0] == 1
+        wl = self.sensorinfo["wl_smac"].T[0]
+        bands = self.sensorinfo["band_id_smac"]
+        # attributes documented at SPART.py:66-81
+        self.R_TOC, self.R_TOA, self.L_TOA, self._La = out["R_TOC"], out["R_TOA"], out["L_TOA"], out["La"]
+        if materialize:
+            sc = scalar
+            col = (lambda a: a[0][:, None].copy()) if sc else (lambda a: a)
+            self.leafopt = LeafOptics(col(out["leaf_refl"]), col(out["leaf_tran"]), col(out["leaf_kchl"]))
+            self.soilopt = SoilOptics(col(out["soil_refl"]), col(out["soil_refl_dry"]))
+            self.canopyopt = CanopyReflectances(*[col(out[k]) for k in ("rso", "rdo", "rsd", "rdd")])
+        if not scalar:
+            return BatchResult(out, wl, bands)
+        table = pd.DataFrame(zip(bands, out["L_TOA"][0], out["R_TOA"][0], out["R_TOC"][0]), index=wl,
+                             columns=["Band", "L_TOA", "R_TOA", "R_TOC"])      # SPART.py:256-260
+        if debug:
+            table["rsoil"] = out["rsoil"][0]                                    # SPART.py:262-267
+        return table

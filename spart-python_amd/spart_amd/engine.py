@@ -1,0 +1,261 @@
+"""Host-side driver of the HIP kernels: one Engine = one libspart_hip context = one
+(device, sensor) pair.  torch tensors are used for device memory and streams only; every
+compute call goes through the C ABI (include/spart_hip.h)."""
+import ctypes
+
+import numpy as np
+
+from . import _lib, tables
+
+DTYPES = {"float32": _lib.SPART_F32, "fp32": _lib.SPART_F32, "f32": _lib.SPART_F32,
+          "float64": _lib.SPART_F64, "fp64": _lib.SPART_F64, "f64": _lib.SPART_F64}
+SMAC_FIELDS = ["Ta_s", "Ta_o", "Tg", "Ra_dd", "Ra_so", "Ta_ss", "Ta_sd", "Ta_oo", "Ta_do"]   # smac.py:209-211
+MATERIALIZE_FIELDS = ["leaf_refl", "leaf_tran", "leaf_kchl", "soil_refl", "soil_refl_dry", "rso", "rdo", "rsd",
+                      "rdd", "rsoil", "La"]
+_MAT_WIDTH = dict(leaf_refl=_lib.NWLS, leaf_tran=_lib.NWLS, leaf_kchl=_lib.NWL, soil_refl=_lib.NWLS,
+                  soil_refl_dry=_lib.NWL, rso=_lib.NWLS, rdo=_lib.NWLS, rsd=_lib.NWLS, rdd=_lib.NWLS)
+
+
+def _require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("spart_amd needs an AMD GPU (HIP device): the evaluator has no CPU path")
+    return torch
+
+
+def _dp(a):
+    return a.ctypes.data_as(_lib.c_dp)
+
+
+class Engine:
+    def __init__(self, sensor=None, device=0, sensor_info=None):
+        torch = _require_gpu()
+        self.lib = _lib.load()
+        self.torch = torch
+        self.device = torch.device("cuda", device)
+        self.sensor = sensor
+        z = tables._npz()
+        keep = {k: np.ascontiguousarray(z[k], dtype=np.float64)
+                for k in ("nr", "Kab", "Kca", "Kdm", "Kw", "Ks", "Kant", "cbc", "prot", "GSV", "nw", "Ea")}
+        t = _lib.SpartTables()
+        for k, v in keep.items():
+            setattr(t, k, _dp(v))
+        self.nb = 0
+        if sensor is not None or sensor_info is not None:
+            si = sensor_info if sensor_info is not None else tables.load_sensor_info(sensor)
+            self.sensor_info = si
+            wl = np.ascontiguousarray(np.asarray(si["wl_smac"], dtype=np.float64).reshape(-1))
+            coef = np.ascontiguousarray(np.stack([np.asarray(si["SMAC_coef"][n], dtype=np.float64).reshape(-1)
+                                                  for n in tables.COEF_NAMES]))
+            wsrf = np.ascontiguousarray(si["wl_srf_smac"], dtype=np.float64)
+            psrf = np.ascontiguousarray(si["p_srf_smac"], dtype=np.float64)
+            keep.update(wl=wl, coef=coef, wsrf=wsrf, psrf=psrf)
+            t.nb, t.wl_smac, t.coef = wl.shape[0], _dp(wl), _dp(coef)
+            t.nsrf, t.wl_srf, t.p_srf = wsrf.shape[0], _dp(wsrf), _dp(psrf)
+            self.nb = int(wl.shape[0])
+            self.wl_smac = np.asarray(si["wl_smac"]).reshape(-1)
+            self.band_id = list(si["band_id_smac"])
+        self._keep = keep
+        ctx = _lib.vp()
+        rc = self.lib.spart_ctx_create(ctypes.byref(ctx), device, ctypes.byref(t))
+        _lib.check(self.lib, None, rc)
+        self.ctx = ctx
+        self._ws_buf = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "ctx", None):
+                self.lib.spart_ctx_destroy(self.ctx)
+                self.ctx = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self):
+        return ctypes.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _workspace(self, dt, B):
+        n = int(self.lib.spart_workspace_bytes(self.ctx, dt, B))
+        if self._ws_buf is None or self._ws_buf.numel() < n:
+            self._ws_buf = self.torch.empty(max(n, 256), dtype=self.torch.uint8, device=self.device)
+        return ctypes.c_void_p(self._ws_buf.data_ptr()), ctypes.c_size_t(self._ws_buf.numel())
+
+    def to_f64(self, x, B=None):
+        """scalar / sequence / numpy / tensor -> contiguous float64 device tensor of length B."""
+        torch = self.torch
+        if not torch.is_tensor(x):
+            x = torch.as_tensor(np.asarray(x, dtype=np.float64))
+        x = x.to(device=self.device, dtype=torch.float64).reshape(-1)
+        if B is not None and x.numel() != B:
+            if x.numel() != 1:
+                raise ValueError(f"parameter of length {x.numel()} does not broadcast to batch {B}")
+            x = x.expand(B)
+        return x.contiguous()
+
+    def columns(self, cols):
+        """list of per-parameter values -> (list of (B,) tensors, B)"""
+        sizes = [int(np.size(c)) if not self.torch.is_tensor(c) else c.numel() for c in cols]
+        B = max(sizes) if sizes else 1
+        return [self.to_f64(c, B) for c in cols], B
+
+    def _ptrs(self, tensors):
+        arr = (_lib.vp * len(tensors))(*[t.data_ptr() if t is not None else None for t in tensors])
+        return arr
+
+    def _tdtype(self, dt):
+        return self.torch.float32 if dt == _lib.SPART_F32 else self.torch.float64
+
+    def _spec(self, x, B, width, dt):
+        torch = self.torch
+        if not torch.is_tensor(x):
+            x = torch.as_tensor(np.asarray(x))
+        x = x.to(device=self.device, dtype=self._tdtype(dt))
+        if x.dim() == 2 and x.shape[1] == 1 and x.shape[0] == width:     # reference style (n,1) column
+            x = x.reshape(1, width)
+        x = x.reshape(-1, x.shape[-1])
+        if x.shape[1] != width:
+            raise ValueError(f"spectrum of length {x.shape[1]}, expected {width}")
+        if x.shape[0] != B:
+            if x.shape[0] != 1:
+                raise ValueError("spectra do not broadcast to the batch")
+            x = x.expand(B, width)
+        return x.contiguous()
+
+    # ------------------------------------------------------------------ operators
+    def prospect(self, leaf9, dtype="float64"):
+        """PROSPECT_5D for a batch (prospect_5d.py:117-246): leaf9 = [Cab,Cdm,Cw,Cs,Cca,Cant,N,PROT,CBC]."""
+        dt = DTYPES[dtype]
+        cols, B = self.columns(leaf9)
+        td = self._tdtype(dt)
+        out = [self.torch.empty((B, _lib.NWL), dtype=td, device=self.device) for _ in range(3)]
+        ws, wsn = self._workspace(dt, B)
+        rc = self.lib.spart_prospect_batch(self.ctx, dt, B, self._ptrs(cols), out[0].data_ptr(), out[1].data_ptr(),
+                                           out[2].data_ptr(), ws, wsn, self._stream())
+        _lib.check(self.lib, self.ctx, rc)
+        return out
+
+    def bsm(self, soil6, dtype="float64", rdry=None):
+        """BSM (bsm.py:17-128): soil6 = [B,lat,lon,SMp,SMC,film]; rdry = optional (B,2001) dry spectra."""
+        dt = DTYPES[dtype]
+        if rdry is not None:
+            soil6 = [0.0 if c is None else c for c in soil6]
+        cols, B = self.columns(soil6)
+        rd = None
+        if rdry is not None:
+            rd0 = rdry if self.torch.is_tensor(rdry) else np.asarray(rdry)
+            nrow = 1 if rd0.ndim == 1 or (rd0.ndim == 2 and rd0.shape[1] == 1) else rd0.shape[0]
+            B = max(B, nrow)
+            cols = [c.expand(B).contiguous() if c.numel() == 1 else c for c in cols]
+            rd = self._spec(rdry, B, _lib.NWL, dt)
+        td = self._tdtype(dt)
+        out = [self.torch.empty((B, _lib.NWL), dtype=td, device=self.device) for _ in range(2)]
+        ws, wsn = self._workspace(dt, B)
+        rc = self.lib.spart_bsm_batch(self.ctx, dt, B, self._ptrs(cols), rd.data_ptr() if rd is not None else None,
+                                      out[0].data_ptr(), out[1].data_ptr(), ws, wsn, self._stream())
+        _lib.check(self.lib, self.ctx, rc)
+        return out
+
+    def lidf(self, LIDFa, LIDFb):
+        cols, B = self.columns([LIDFa, LIDFb])
+        out = self.torch.empty((B, _lib.NLINCL), dtype=self.torch.float64, device=self.device)
+        rc = self.lib.spart_lidf_batch(self.ctx, B, cols[0].data_ptr(), cols[1].data_ptr(), out.data_ptr(),
+                                       self._stream())
+        _lib.check(self.lib, self.ctx, rc)
+        return out
+
+    def sailh(self, rho, tau, rs, canopy4, angles3, dtype="float64"):
+        """SAILH (sailh.py:14-237) on (B,2162) spectra."""
+        dt = DTYPES[dtype]
+        cols, B = self.columns(list(canopy4) + list(angles3))
+        for x in (rho, tau, rs):
+            n = x.shape[0] if (hasattr(x, "ndim") and x.ndim == 2 and x.shape[1] != 1) else 1
+            B = max(B, n)
+        cols = [c.expand(B).contiguous() if c.numel() == 1 else c for c in cols]
+        rho, tau, rs = (self._spec(x, B, _lib.NWLS, dt) for x in (rho, tau, rs))
+        td = self._tdtype(dt)
+        out = [self.torch.empty((B, _lib.NWLS), dtype=td, device=self.device) for _ in range(4)]
+        ws, wsn = self._workspace(dt, B)
+        rc = self.lib.spart_sailh_batch(self.ctx, dt, B, rho.data_ptr(), tau.data_ptr(), rs.data_ptr(),
+                                        self._ptrs(cols[:4]), self._ptrs(cols[4:]), self._ptrs(out), ws, wsn,
+                                        self._stream())
+        _lib.check(self.lib, self.ctx, rc)
+        return out
+
+    def smac(self, angles3, atm4):
+        """SMAC (smac.py:14-213): nine (B,nb) float64 tensors in AtmosphericOptics order."""
+        cols, B = self.columns(list(angles3) + list(atm4))
+        out = [self.torch.empty((B, self.nb), dtype=self.torch.float64, device=self.device) for _ in range(9)]
+        ws, wsn = self._workspace(_lib.SPART_F64, B)
+        rc = self.lib.spart_smac_batch(self.ctx, B, self._ptrs(cols[:3]), self._ptrs(cols[3:]), self._ptrs(out), ws, wsn,
+                                       self._stream())
+        _lib.check(self.lib, self.ctx, rc)
+        return dict(zip(SMAC_FIELDS, out))
+
+    def run(self, params, dtype="float32", rho_thermal=None, tau_thermal=None, materialize=(), out=None):
+        """SPART(...).run() for every column of ``params`` (SPART.py:162-269).
+
+        params : (27, B) float64 device tensor (rows = spart_amd.workloads.PARAM_NAMES) or a list of 27
+                 scalars / arrays.
+        materialize : iterable of names from MATERIALIZE_FIELDS to also return (full spectra etc.)
+        out : optional dict with preallocated 'R_TOC','R_TOA','L_TOA' (B,nb) tensors
+        """
+        torch = self.torch
+        dt = DTYPES[dtype]
+        td = self._tdtype(dt)
+        if torch.is_tensor(params) and params.dim() == 2:
+            if params.shape[0] != _lib.NPARAM:
+                raise ValueError("params must be (27, B)")
+            P = params.to(device=self.device, dtype=torch.float64).contiguous()
+            B = P.shape[1]
+            cols = [P[i] for i in range(_lib.NPARAM)]
+        else:
+            cols, B = self.columns(list(params))
+        th = [None if x is None else self.to_f64(x, B) for x in (rho_thermal, tau_thermal)]
+        res = out if out is not None else {}
+        for k in ("R_TOC", "R_TOA", "L_TOA"):
+            if k not in res:
+                res[k] = torch.empty((B, self.nb), dtype=td, device=self.device)
+        mat = None
+        if materialize:
+            mat = _lib.SpartMaterialize()
+            for name in materialize:
+                if name not in MATERIALIZE_FIELDS:
+                    raise ValueError(f"unknown materialize field {name}")
+                width = _MAT_WIDTH.get(name, self.nb)
+                res[name] = torch.empty((B, width), dtype=td, device=self.device)
+                setattr(mat, name, res[name].data_ptr())
+        ws, wsn = self._workspace(dt, B)
+        rc = self.lib.spart_run_batch(self.ctx, dt, B, self._ptrs(cols), th[0].data_ptr() if th[0] is not None else None,
+                                      th[1].data_ptr() if th[1] is not None else None, res["R_TOC"].data_ptr(),
+                                      res["R_TOA"].data_ptr(), res["L_TOA"].data_ptr(),
+                                      ctypes.byref(mat) if mat is not None else None, ws, wsn, self._stream())
+        _lib.check(self.lib, self.ctx, rc)
+        return res
+
+    def profile(self, max_calls):
+        """bracket the band kernel of the next ``max_calls`` run() calls with HIP events (0 = off)."""
+        _lib.check(self.lib, self.ctx, self.lib.spart_profile_enable(self.ctx, int(max_calls)))
+
+    def profile_read(self):
+        """-> (summed band-kernel milliseconds, number of timed calls)"""
+        ms, n = ctypes.c_double(0.0), ctypes.c_int(0)
+        _lib.check(self.lib, self.ctx, self.lib.spart_profile_read(self.ctx, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
+
+    def econv(self):
+        out = np.zeros(self.nb)
+        _lib.check(self.lib, self.ctx, self.lib.spart_ctx_econv(self.ctx, _dp(out)))
+        return out
+
+
+_engines = {}
+
+
+def get_engine(sensor=None, device=None):
+    torch = _require_gpu()
+    if device is None:
+        device = torch.cuda.current_device()
+    key = (sensor, int(device))
+    if key not in _engines:
+        _engines[key] = Engine(sensor, int(device))
+    return _engines[key]

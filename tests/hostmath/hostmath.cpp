@@ -1,0 +1,103 @@
+// TEST INFRASTRUCTURE ONLY: compiles the device arithmetic header (csrc/spart_math.h) with
+// g++ so that the float32 / float64 formulations can be checked against the oracle on a
+// machine without a GPU (tests/test_hostmath.py).  Nothing in spart-python_amd/ loads this.
+#include <cstdint>
+#include <cstring>
+
+#include "../../spart-python_amd/csrc/spart_math.h"
+
+using namespace spart;
+
+template <typename T> static BandTab<T> tab_at(const double* tab, int i) {
+  BandTab<T> t;
+  t.kab = (T)tab[TAB_KAB * NWL + i]; t.kca = (T)tab[TAB_KCA * NWL + i]; t.kdm = (T)tab[TAB_KDM * NWL + i];
+  t.kw = (T)tab[TAB_KW * NWL + i]; t.ks = (T)tab[TAB_KS * NWL + i]; t.kant = (T)tab[TAB_KANT * NWL + i];
+  t.kcbc = (T)tab[TAB_CBC * NWL + i]; t.kprot = (T)tab[TAB_PROT * NWL + i]; t.talf = (T)tab[TAB_TALF * NWL + i];
+  t.t12 = (T)tab[TAB_T12 * NWL + i]; t.t21 = (T)tab[TAB_T21 * NWL + i]; t.g0 = (T)tab[TAB_GSV0 * NWL + i];
+  t.g1 = (T)tab[TAB_GSV1 * NWL + i]; t.g2 = (T)tab[TAB_GSV2 * NWL + i]; t.cbac = (T)tab[TAB_CBAC * NWL + i];
+  t.pw = (T)tab[TAB_PW * NWL + i]; t.rw = (T)tab[TAB_RW * NWL + i];
+  return t;
+}
+
+template <typename T>
+static void bands_impl(int64_t B, const double* tab, const double* P, double* out /* (B, NEVAL, 10) */,
+                       double* atm_out, double* lidf_out) {
+  for (int64_t s = 0; s < B; ++s) {
+    T c[NCONST];
+    double a[NATM], li[NLINCL];
+    sample_prelude<T>(P + s * NPARAM, 0.01, 0.01, PRE_ALL, c, a, li);
+    std::memcpy(atm_out + s * NATM, a, sizeof(a));
+    std::memcpy(lidf_out + s * NLINCL, li, sizeof(li));
+    CanopyPar<T> cp;
+    cp.sdb = c[C_SDB]; cp.sdf = c[C_SDF]; cp.ddb = c[C_DDB]; cp.ddf = c[C_DDF]; cp.dob = c[C_DOB]; cp.dof = c[C_DOF];
+    cp.sob = c[C_SOB]; cp.sof = c[C_SOF]; cp.bf = c[C_BF]; cp.ks = c[C_KS]; cp.ko = c[C_KO]; cp.lai = c[C_LAI];
+    cp.tss = c[C_TSS]; cp.too = c[C_TOO]; cp.Z = c[C_Z]; cp.hot = c[C_HOT]; cp.pso2w = c[C_PSO2W];
+    for (int band = 0; band < NEVAL; ++band) {
+      bool thermal = band == NWL;
+      BandTab<T> tb = tab_at<T>(tab, thermal ? NWL - 1 : band);
+      T refl, tran, absb, K;
+      leaf_band<T>(tb, c[C_CAB], c[C_CCA], c[C_CDM], c[C_CW], c[C_CS], c[C_CANT], c[C_CBC], c[C_PROT], c[C_NM1], refl, tran,
+                   absb, K);
+      T rdry = soil_dry<T>(tb, c[C_F1], c[C_F2], c[C_F3]);
+      T fm[7] = {c[C_FM0], c[C_FM1], c[C_FM2], c[C_FM3], c[C_FM4], c[C_FM5], c[C_FM6]};
+      T rwet;
+      soil_band<T>(tb, rdry, c[C_WET], fm, c[C_FILM2], rwet);
+      T rho = thermal ? c[C_RHO_TH] : refl, tau = thermal ? c[C_TAU_TH] : tran;
+      T ab = thermal ? (T(1) - c[C_RHO_TH] - c[C_TAU_TH]) : absb;
+      T rso, rdo, rsd, rdd;
+      canopy_band<T>(cp, rho, tau, ab, rwet, rso, rdo, rsd, rdd);
+      double* o = out + ((size_t)s * NEVAL + band) * 10;
+      o[0] = rho; o[1] = tau; o[2] = (K > T(0)) ? (double)(c[C_CAB] * tb.kab / K) : 0.0; o[3] = rdry; o[4] = rwet;
+      o[5] = rso; o[6] = rdo; o[7] = rsd; o[8] = rdd; o[9] = ab;
+    }
+  }
+}
+
+extern "C" {
+
+void hm_derive_tables(const double* nr, const double* nw, const double* Kab, const double* Kca, const double* Kdm,
+                      const double* Kw, const double* Ks, const double* Kant, const double* cbc, const double* prot,
+                      const double* GSV, double* tab) {
+  const double tav90_2 = calculate_tav(90, 2.0);
+  for (int i = 0; i < NWL; ++i) {
+    tab[TAB_KAB * NWL + i] = Kab[i]; tab[TAB_KCA * NWL + i] = Kca[i]; tab[TAB_KDM * NWL + i] = Kdm[i];
+    tab[TAB_KW * NWL + i] = Kw[i]; tab[TAB_KS * NWL + i] = Ks[i]; tab[TAB_KANT * NWL + i] = Kant[i];
+    tab[TAB_CBC * NWL + i] = cbc[i]; tab[TAB_PROT * NWL + i] = prot[i];
+    double t12 = calculate_tav(90, nr[i]);
+    tab[TAB_TALF * NWL + i] = calculate_tav(40, nr[i]); tab[TAB_T12 * NWL + i] = t12; tab[TAB_T21 * NWL + i] = t12 / (nr[i] * nr[i]);
+    tab[TAB_GSV0 * NWL + i] = GSV[3 * i]; tab[TAB_GSV1 * NWL + i] = GSV[3 * i + 1]; tab[TAB_GSV2 * NWL + i] = GSV[3 * i + 2];
+    tab[TAB_CBAC * NWL + i] = calculate_tav(90, 2.0 / nw[i]) / tav90_2;
+    tab[TAB_PW * NWL + i] = 1.0 - calculate_tav(90, nw[i]) / (nw[i] * nw[i]);
+    tab[TAB_RW * NWL + i] = 1.0 - calculate_tav(40, nw[i]);
+  }
+}
+
+// out: (B, 2002, 10) = rho, tau, kchl, rdry, rwet, rso, rdo, rsd, rdd, absorptance
+void hm_bands(int dtype, int64_t B, const double* tab, const double* P, double* out, double* atm, double* lidf) {
+  if (dtype == 0) bands_impl<float>(B, tab, P, out, atm, lidf);
+  else bands_impl<double>(B, tab, P, out, atm, lidf);
+}
+
+// SMAC + TOC->TOA for (B, nb): rv (B, nb, 4) = rso, rdo, rsd, rdd at the band centres
+void hm_sensor(int64_t B, int nb, const double* atm, const double* coef, const double* econv, const double* rv,
+               double* smac9 /* (B,nb,9) */, double* toa3 /* (B,nb,3) */) {
+  for (int64_t s = 0; s < B; ++s)
+    for (int j = 0; j < nb; ++j) {
+      SmacOut so = smac_band(atm + s * NATM, coef + j, nb);
+      double* o = smac9 + ((size_t)s * nb + j) * 9;
+      o[0] = so.Ta_s; o[1] = so.Ta_o; o[2] = so.Tg; o[3] = so.Ra_dd; o[4] = so.Ra_so; o[5] = so.Ta_ss; o[6] = so.Ta_sd;
+      o[7] = so.Ta_oo; o[8] = so.Ta_do;
+      const double* v = rv + ((size_t)s * nb + j) * 4;
+      double La = atm[s * NATM + A_LAF] * econv[j];
+      double* t = toa3 + ((size_t)s * nb + j) * 3;
+      toc_to_toa(so, v[0], v[1], v[3], v[2], La, t[0], t[1], t[2]);
+    }
+}
+
+void hm_plate_tau(int dtype, int64_t n, const double* K, double* tau, double* u) {
+  for (int64_t i = 0; i < n; ++i) {
+    if (dtype == 0) { float t, uu; plate_tau<float>((float)K[i], t, uu); tau[i] = t; u[i] = uu; }
+    else { double t, uu; plate_tau<double>(K[i], t, uu); tau[i] = t; u[i] = uu; }
+  }
+}
+}

@@ -1,0 +1,201 @@
+"""Parity of the HIP path (through the C ABI, via spart_amd.Engine) with the oracle and with the
+reference's golden vectors.  Tolerances: north_star's 1e-6 rel (fp64) / 1e-4 rel (fp32) on the
+sensor columns; spectra use the same relative bound with an absolute floor matching the
+reference's own unit-test precision (assert_almost_equal: 1.5e-7 leaf, 1.5e-6 canopy)."""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"float64": 1e-6, "float32": 1e-4}
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
+
+
+def test_native_library_is_loaded(torch_mod):
+    from spart_amd import _lib
+    lib = _lib.load()
+    assert lib is not None
+    with open("/proc/self/maps") as f:
+        assert "libspart_hip.so" in f.read()
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_prospect_golden(golden, dtype, torch_mod):
+    from spart_amd import get_engine
+    g = golden["prospect"]
+    eng = get_engine(None, 0)
+    refl, tran, kchl = eng.prospect(list(g["leaf"].T), dtype)
+    tol = TOL[dtype]
+    # floors: reflectance is O(0.05..0.5); transmittance / kChlrel go to ~0 -> absolute floor 1e-2 * tol-scale
+    assert rel_err(refl.cpu().numpy(), g["refl"], 1e-2) < tol
+    assert rel_err(tran.cpu().numpy(), g["tran"], 1e-2) < tol
+    assert rel_err(kchl.cpu().numpy(), g["kChlrel"], 1e-2) < tol
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_bsm_golden(golden, dtype, torch_mod):
+    from spart_amd import get_engine
+    g = golden["bsm"]
+    eng = get_engine(None, 0)
+    refl, dry = eng.bsm(list(g["soil"].T), dtype)
+    assert rel_err(refl.cpu().numpy(), g["refl"], 1e-2) < TOL[dtype]
+    assert rel_err(dry.cpu().numpy(), g["refl_dry"], 1e-2) < TOL[dtype]
+
+
+def test_lidf_golden(golden, torch_mod):
+    from spart_amd import get_engine
+    g = golden["sailh"]
+    eng = get_engine(None, 0)
+    lidf = eng.lidf(g["canopy"][:, 1], g["canopy"][:, 2]).cpu().numpy()
+    assert np.max(np.abs(lidf - g["lidf"])) < 1e-12
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_sailh_golden(golden, dtype, torch_mod):
+    from spart_amd import get_engine
+    g = golden["sailh"]
+    eng = get_engine(None, 0)
+    out = eng.sailh(g["leaf_refl"][None], g["leaf_tran"][None], g["soil_refl"][None], list(g["canopy"].T),
+                    list(g["angles"].T), dtype)
+    for o, k in zip(out, ("rso", "rdo", "rsd", "rdd")):
+        assert rel_err(o.cpu().numpy(), g[k], 1e-2) < TOL[dtype], k
+
+
+@pytest.mark.parametrize("sensor", ["Sentinel2A-MSI", "Sentinel2B-MSI", "TerraAqua-MODIS", "LANDSAT7-ETM",
+                                    "LANDSAT8-OLI", "Sentinel3A-OLCI"])
+def test_smac_golden(golden, sensor, torch_mod):
+    from spart_amd import get_engine
+    from spart_amd.engine import SMAC_FIELDS
+    g = golden["smac"]
+    eng = get_engine(sensor, 0)
+    out = eng.smac(list(g[f"{sensor}/angles"].T), list(g[f"{sensor}/atm"].T))
+    # the Sentinel-2 pickles hold float32 coefficients and the reference then computes partly in float32
+    tol = 2e-6 if sensor.startswith("Sentinel2") else 1e-9
+    for f in SMAC_FIELDS:
+        assert rel_err(out[f].cpu().numpy(), g[f"{sensor}/{f}"], 1e-3) < tol, f
+
+
+def _e2e_groups(golden):
+    g = golden["e2e"]
+    return sorted(set(k.rsplit("/", 1)[0] for k in g.files))
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_full_chain_golden(golden, dtype, torch_mod):
+    """Every committed full-chain row of the reference: 9 sensors x defaults, README/MODIS (NaN leaf
+    bands), PRO/S2B, the config-4 and config-5 LHS slices."""
+    from spart_amd import get_engine
+    g = golden["e2e"]
+    worst = {}
+    for name in _e2e_groups(golden):
+        sensor = name.split("/")[1]
+        eng = get_engine(sensor, 0)
+        P = torch_mod.as_tensor(g[name + "/P"].T.copy(), device="cuda:0")
+        out = eng.run(P, dtype, materialize=("rsoil", "La"))
+        for k in ("R_TOC", "R_TOA", "L_TOA", "rsoil", "La"):
+            e = rel_err(out[k].cpu().numpy(), g[f"{name}/{k}"], 1e-3)
+            worst[(name, k)] = e
+            assert e < TOL[dtype], (name, k, e)
+    print({k: f"{v:.1e}" for k, v in worst.items() if v > 0.1 * TOL[dtype]})
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_full_chain_vs_oracle_spectra(oracle, tables, dtype, torch_mod):
+    """Materialised leaf / soil / canopy spectra of the fused kernel against the oracle (seeded LHS)."""
+    from spart_amd import get_engine, workloads
+    P = workloads.lhs_params(96, "full", seed=5)
+    ref = oracle.spart_run(P, "Sentinel2A-MSI", tables, pso="gl", full=True)
+    eng = get_engine("Sentinel2A-MSI", 0)
+    fields = ("leaf_refl", "leaf_tran", "leaf_kchl", "soil_refl", "soil_refl_dry", "rso", "rdo", "rsd", "rdd")
+    out = eng.run(torch_mod.as_tensor(P.T.copy(), device="cuda:0"), dtype, materialize=fields)
+    rho, tau = oracle.pad_leaf(ref["leaf_refl"], ref["leaf_tran"])
+    expect = dict(leaf_refl=rho, leaf_tran=tau, leaf_kchl=ref["kChlrel"], soil_refl=oracle.pad_soil(ref["soil_refl"]),
+                  soil_refl_dry=ref["soil_refl_dry"], rso=ref["rso"], rdo=ref["rdo"], rsd=ref["rsd"], rdd=ref["rdd"])
+    for k in fields:
+        assert rel_err(out[k].cpu().numpy(), expect[k], 1e-2) < TOL[dtype], k
+    for k in ("R_TOC", "R_TOA", "L_TOA"):
+        assert rel_err(out[k].cpu().numpy(), ref[k], 1e-3) < TOL[dtype], k
+
+
+def test_ragged_and_edge_batches(oracle, tables, torch_mod):
+    """B = 1, B not a multiple of the chunk / workgroup size, B = 0."""
+    from spart_amd import get_engine, workloads
+    eng = get_engine("Sentinel2A-MSI", 0)
+    for B in (1, 7, 65, 257):
+        P = workloads.lhs_params(B, "full", seed=B)
+        ref = oracle.spart_run(P, "Sentinel2A-MSI", tables, pso="gl")
+        out = eng.run(torch_mod.as_tensor(P.T.copy(), device="cuda:0"), "float64")
+        for k in ("R_TOC", "R_TOA", "L_TOA"):
+            assert rel_err(out[k].cpu().numpy(), ref[k], 1e-3) < 1e-6
+    out = eng.run(torch_mod.zeros((27, 0), dtype=torch_mod.float64, device="cuda:0"), "float32")
+    assert out["R_TOC"].shape == (0, 13)
+
+
+def test_full_size_properties(torch_mod):
+    """BASELINE size (1M spectra, fp32): size-independent checks -- finite, positive-band sanity
+    against a 4096-row fp64 re-evaluation of scattered rows, and batch-split invariance."""
+    from spart_amd import get_engine, workloads
+    eng = get_engine("Sentinel2A-MSI", 0)
+    B = 1_000_000
+    P = torch_mod.as_tensor(workloads.lhs_params(B, "full").T.copy(), device="cuda:0")
+    out = eng.run(P, "float32")
+    for k in ("R_TOC", "R_TOA", "L_TOA"):
+        assert torch_mod.isfinite(out[k]).all()
+    idx = torch_mod.arange(0, B, B // 4096, device="cuda:0")[:4096]
+    sub = eng.run(P[:, idx].contiguous(), "float64")
+    for k in ("R_TOC", "R_TOA", "L_TOA"):
+        a, b = out[k][idx].double(), sub[k]
+        err = ((a - b).abs() / b.abs().clamp_min(1e-3)).max().item()
+        assert err < 1e-4, (k, err)
+    # evaluating the batch in two halves gives bit-identical columns (samples are independent)
+    h = B // 2 + 13
+    o1 = eng.run(P[:, :h].contiguous(), "float32")
+    o1 = {k: v.clone() for k, v in o1.items()}
+    o2 = eng.run(P[:, h:].contiguous(), "float32")
+    for k in ("R_TOC", "R_TOA", "L_TOA"):
+        assert torch_mod.equal(torch_mod.cat([o1[k], o2[k]]), out[k])
+
+
+def test_reference_style_api(golden, torch_mod, capsys):
+    """import SPART; SPART.SPART(...).run() -> the reference's DataFrame (README quickstart pins)."""
+    import SPART
+    leafbio = SPART.LeafBiology(40, 10, 0.02, 0.01, 0, 10, 1.5)
+    soilpar = SPART.SoilParameters(0.5, 0, 100, 15, 25, 0.015)
+    canopy = SPART.CanopyStructure(3, -0.35, -0.15, 0.05)
+    angles = SPART.Angles(40, 0, 0)
+    atm = SPART.AtmosphericProperties(0.3246, 0.3480, 1.4116, 1013.25)
+    df = SPART.SPART(soilpar, leafbio, canopy, atm, angles, "TerraAqua-MODIS", 100).run(debug=True)
+    assert list(df.columns) == ["Band", "L_TOA", "R_TOA", "R_TOC", "rsoil"]
+    assert abs(df["R_TOC"].iloc[0] / 0.02087402205273674 - 1) < 1e-6
+    assert abs(df["R_TOA"].iloc[0] / 0.0497552219811317 - 1) < 1e-6
+    assert abs(df["L_TOA"].iloc[0] / 0.022812529362725764 - 1) < 1e-6
+    g = golden["e2e"]
+    assert rel_err(df["R_TOA"].to_numpy(), g["readme/TerraAqua-MODIS/R_TOA"][0], 1e-3) < 1e-6
+    # PROSPECT-PRO warning text goes to stdout once (prospect_5d.py:148-155)
+    pro = SPART.LeafBiology(40, 0.01, 0.02, 0, 10, 10, 1.5, PROT=0.001, CBC=0.009)
+    df2 = SPART.SPART(SPART.SoilParameters(0.5, 0, 100, 20, 25, 0.015), pro, canopy,
+                      SPART.AtmosphericProperties(0.325, 0.35, 1.41), angles, "Sentinel2B-MSI", 100).run()
+    assert "PROSPECT-PRO was called" in capsys.readouterr().out
+    assert abs(df2["R_TOC"].iloc[0] / 0.016457380856374198 - 1) < 1e-6
+    assert abs(df2["R_TOA"].iloc[5] / 0.3058118531440649 - 1) < 1e-6
+    # stage functions with reference shapes
+    lo = SPART.PROSPECT_5D(SPART.LeafBiology(40, 0.01, 0.02, 0, 10, 10, 1.5), SPART.load_optical_parameters())
+    assert lo.refl.shape == (2001, 1)
+    assert abs(lo.refl[150, 0] - 0.06375474885800862) < 1e-7 and abs(lo.tran[400, 0] - 0.4700377848758272) < 1e-7
+    with pytest.raises(RuntimeError, match="must be of len 2162"):
+        SPART.SAILH(SPART.BSM(soilpar), lo, canopy, angles)
+    lo = SPART.set_leaf_refl_trans_assumptions(lo, leafbio, SPART.SpectralBands())
+    so = SPART.set_soil_refl_trans_assumptions(SPART.BSM(SPART.SoilParameters(0.5, 0, 100, 20, 25, 0.015)),
+                                               SPART.SpectralBands())
+    rad = SPART.SAILH(so, lo, canopy, angles)
+    assert rad.rso.shape == (2162, 1)
+    assert abs(rad.rso[400, 0] - 0.40396347479496547) < 1e-6 and abs(rad.rdd[2100, 0] - 0.005657296144770152) < 1e-6
+    assert abs(canopy.lidf[0, 0] - 0.037891833294514) < 1e-12
