@@ -55,7 +55,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1_000_000, help="spectra per GPU per step")
     ap.add_argument("--dtype", default="float32", choices=["float32", "float64"])
     ap.add_argument("--sensor", default="Sentinel2A-MSI")
-    ap.add_argument("--cpu-rows", type=int, default=4096, help="rows for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-rows", type=int, default=32768, help="rows for the CPU baseline (0 = skip)")
     args = ap.parse_args()
 
     import numpy as np

@@ -10,6 +10,10 @@ from conftest import rel_err
 pytestmark = pytest.mark.gpu
 
 TOL = {"float64": 1e-6, "float32": 1e-4}
+# |a-b| <= TOL * max(|b|, FLOOR): the floor turns the bound into an absolute one for near-zero
+# spectra (1e-7 in fp64 = the reference's own assert_almost_equal precision and its E1-quadrature
+# noise; 1e-6 in fp32)
+FLOOR = {"float64": 0.1, "float32": 1e-2}
 
 
 @pytest.fixture(scope="module")
@@ -33,11 +37,10 @@ def test_prospect_golden(golden, dtype, torch_mod):
     g = golden["prospect"]
     eng = get_engine(None, 0)
     refl, tran, kchl = eng.prospect(list(g["leaf"].T), dtype)
-    tol = TOL[dtype]
-    # floors: reflectance is O(0.05..0.5); transmittance / kChlrel go to ~0 -> absolute floor 1e-2 * tol-scale
-    assert rel_err(refl.cpu().numpy(), g["refl"], 1e-2) < tol
-    assert rel_err(tran.cpu().numpy(), g["tran"], 1e-2) < tol
-    assert rel_err(kchl.cpu().numpy(), g["kChlrel"], 1e-2) < tol
+    tol, fl = TOL[dtype], FLOOR[dtype]
+    assert rel_err(refl.cpu().numpy(), g["refl"], fl) < tol
+    assert rel_err(tran.cpu().numpy(), g["tran"], fl) < tol
+    assert rel_err(kchl.cpu().numpy(), g["kChlrel"], fl) < tol
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
@@ -46,8 +49,8 @@ def test_bsm_golden(golden, dtype, torch_mod):
     g = golden["bsm"]
     eng = get_engine(None, 0)
     refl, dry = eng.bsm(list(g["soil"].T), dtype)
-    assert rel_err(refl.cpu().numpy(), g["refl"], 1e-2) < TOL[dtype]
-    assert rel_err(dry.cpu().numpy(), g["refl_dry"], 1e-2) < TOL[dtype]
+    assert rel_err(refl.cpu().numpy(), g["refl"], FLOOR[dtype]) < TOL[dtype]
+    assert rel_err(dry.cpu().numpy(), g["refl_dry"], FLOOR[dtype]) < TOL[dtype]
 
 
 def test_lidf_golden(golden, torch_mod):
@@ -66,7 +69,7 @@ def test_sailh_golden(golden, dtype, torch_mod):
     out = eng.sailh(g["leaf_refl"][None], g["leaf_tran"][None], g["soil_refl"][None], list(g["canopy"].T),
                     list(g["angles"].T), dtype)
     for o, k in zip(out, ("rso", "rdo", "rsd", "rdd")):
-        assert rel_err(o.cpu().numpy(), g[k], 1e-2) < TOL[dtype], k
+        assert rel_err(o.cpu().numpy(), g[k], FLOOR[dtype]) < TOL[dtype], k
 
 
 @pytest.mark.parametrize("sensor", ["Sentinel2A-MSI", "Sentinel2B-MSI", "TerraAqua-MODIS", "LANDSAT7-ETM",
@@ -120,7 +123,7 @@ def test_full_chain_vs_oracle_spectra(oracle, tables, dtype, torch_mod):
     expect = dict(leaf_refl=rho, leaf_tran=tau, leaf_kchl=ref["kChlrel"], soil_refl=oracle.pad_soil(ref["soil_refl"]),
                   soil_refl_dry=ref["soil_refl_dry"], rso=ref["rso"], rdo=ref["rdo"], rsd=ref["rsd"], rdd=ref["rdd"])
     for k in fields:
-        assert rel_err(out[k].cpu().numpy(), expect[k], 1e-2) < TOL[dtype], k
+        assert rel_err(out[k].cpu().numpy(), expect[k], FLOOR[dtype]) < TOL[dtype], k
     for k in ("R_TOC", "R_TOA", "L_TOA"):
         assert rel_err(out[k].cpu().numpy(), ref[k], 1e-3) < TOL[dtype], k
 
