@@ -4,7 +4,7 @@ import sys
 import pytest
 
 ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-for p in (os.path.join(ROOT, "spart-python_amd"), os.path.join(ROOT, "oracle"), ROOT):
+for p in (os.path.join(ROOT, "spart-python_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"), ROOT):
     if p not in sys.path:
         sys.path.insert(0, p)
 

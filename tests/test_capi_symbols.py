@@ -1,0 +1,58 @@
+"""The C-ABI library builds for gfx950 (hipcc cross-compiles without a GPU), loads, and exports
+every function include/spart_hip.h declares.  No compute calls here."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def lib_path():
+    sys.path.insert(0, os.path.join(ROOT, "spart-python_amd"))
+    import build
+    return build.build(verbose=False)
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "spart_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(spart_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_declares_the_documented_entry_points():
+    names = declared_functions()
+    for n in ("spart_ctx_create", "spart_ctx_destroy", "spart_last_error", "spart_workspace_bytes",
+              "spart_prospect_batch", "spart_bsm_batch", "spart_lidf_batch", "spart_sailh_batch", "spart_smac_batch",
+              "spart_run_batch"):
+        assert n in names
+
+
+def test_library_exports_every_declared_symbol(lib_path):
+    lib = ctypes.CDLL(lib_path)
+    for n in declared_functions():
+        assert hasattr(lib, n), f"{n} declared in include/spart_hip.h but not exported"
+
+
+def test_ctypes_signatures_cover_the_header(lib_path):
+    from spart_amd import _lib
+    assert sorted(_lib.SIGNATURES) == declared_functions()
+    _lib.load()
+
+
+def test_code_object_targets_gfx950(lib_path):
+    data = open(lib_path, "rb").read()
+    assert b"amdgcn-amd-amdhsa--gfx950" in data
+
+
+def test_null_context_errors_do_not_need_a_gpu(lib_path):
+    lib = ctypes.CDLL(lib_path)
+    lib.spart_last_error.restype = ctypes.c_char_p
+    lib.spart_workspace_bytes.restype = ctypes.c_size_t
+    assert lib.spart_workspace_bytes(None, 0, ctypes.c_int64(10)) == 0
+    rc = lib.spart_ctx_create(None, 0, None)
+    assert rc == -1 and b"null" in lib.spart_last_error(None)

@@ -1,0 +1,102 @@
+"""Host-side behaviour that needs no GPU: constructor surface, defaults, warnings, error types,
+workload generator, and the loud failure of compute entry points without a HIP device."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+gpu_absent = not torch.cuda.is_available()
+
+
+def test_constructor_surface_matches_reference():
+    import SPART
+    lb = SPART.LeafBiology(40, 0.01, 0.02, 0, 10, 10, 1.5)          # prospect_5d.py:73-83 positional order
+    assert (lb.Cab, lb.Cdm, lb.Cw, lb.Cs, lb.Cca, lb.Cant, lb.N) == (40, 0.01, 0.02, 0, 10, 10, 1.5)
+    assert (lb.PROT, lb.CBC, lb.rho_thermal, lb.tau_thermal) == (0.0, 0.0, 0.01, 0.01)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        sp = SPART.SoilParameters(0.5, 0, 100, 15)                  # bsm.py:274-286
+    assert sp.SMC == 25 and sp.film == 0.0150 and sp.rdry_set is False and len(w) == 2
+    assert "SMC not supplied" in str(w[0].message)
+    cs = SPART.CanopyStructure(3, -0.35, -0.15, 0.05)               # sailh.py:340-348
+    assert (cs.nlayers, cs.nlincl, cs.nlazi) == (60, 13, 36)
+    a = SPART.Angles(40, 0, 0)
+    assert (a.sol_angle, a.obs_angle, a.rel_angle) == (40, 0, 0)
+    assert SPART.AtmosphericProperties(0.3, 0.3, 1.4).Pa == 1013.25  # smac.py:307-317
+    p = SPART.AtmosphericProperties(0.3, 0.3, 1.4, alt_m=500, temp_k=290).Pa
+    assert abs(p - 1013.25 * np.exp(-(9.80665 * 500 * 0.02896968 / (290 * 8.314462618)))) < 1e-12
+    from SPART.bsm import BSM, SoilParameters  # noqa: F401  submodule aliases as in the reference tree
+    from SPART.prospect_5d import PROSPECT_5D, LeafBiology  # noqa: F401
+    from SPART.sailh import SAILH, Angles, CanopyStructure  # noqa: F401
+    from SPART.smac import SMAC, AtmosphericProperties  # noqa: F401
+
+
+def test_spectral_bands_and_loaders():
+    import SPART
+    sb = SPART.SpectralBands()
+    assert sb.nwlP == 2001 and sb.nwlT == 161 and sb.wlS.shape == (2162,) and sb.wlS[2001] == 2500
+    op = SPART.load_optical_parameters()
+    assert op["Kab"].shape == (2001, 1) and op["GSV"].shape == (2001, 3)
+    si = SPART.load_sensor_info("Sentinel2A-MSI")
+    assert si["wl_smac"].shape == (13, 1) and si["wl_smac"].dtype == np.uint16 and len(si["SMAC_coef"]) == 48
+    with pytest.raises(FileNotFoundError):
+        SPART.load_sensor_info("Sentinel9Z")
+    with pytest.raises(FileNotFoundError):
+        SPART.SPART(None, None, None, None, None, "Sentinel9Z", 100)
+
+
+def test_padding_helpers_follow_reference(oracle, tables):
+    import SPART
+    refl = np.linspace(0.1, 0.2, 2001)[:, None]
+    so = SPART.set_soil_refl_trans_assumptions(SPART.SoilOptics(refl.copy(), refl.copy()), SPART.SpectralBands())
+    assert so.refl.shape == (2162, 1) and np.all(so.refl[2001:] == refl[2000])
+    lo = SPART.LeafOptics(refl.copy(), refl.copy() * 2, refl.copy())
+    lo = SPART.set_leaf_refl_trans_assumptions(lo, SPART.LeafBiology(1, 1, 1, 1, 1, 1, 1), SPART.SpectralBands())
+    assert lo.refl.shape == (2162, 1) and np.all(lo.refl[2001:] == 0.01) and np.all(lo.tran[2001:] == 0.01)
+    # ET radiance + SRF convolution host helpers equal the oracle's
+    si = SPART.load_sensor_info("TerraAqua-MODIS")
+    Ra = SPART.calculate_ET_radiance(SPART.load_ET_parameters()["Ea"], 100, 40)
+    La = SPART.calculate_spectral_convolution(SPART.load_ET_parameters()["wl_Ea"], Ra, si)
+    se = oracle.sensor_tables(tables, "TerraAqua-MODIS")
+    ref = oracle.et_correction(100) * np.cos(40 * np.pi / 180) / np.pi * oracle.et_convolution(tables, se)
+    assert np.allclose(La, ref, rtol=1e-13)
+
+
+def test_workloads():
+    from spart_amd import workloads as W
+    P = W.lhs_params(1000, "full")
+    assert P.shape == (1000, 27)
+    for name, (lo, hi) in W.RANGES.items():
+        if name in ("PROT", "CBC"):
+            continue
+        col = P[:, W.PARAM_NAMES.index(name)]
+        assert lo <= col.min() and col.max() <= hi
+    assert np.all(P[:, W.PARAM_NAMES.index("SMC")] == 25) and np.all(P[:, 26] == 100)
+    Q = W.lhs_params(1000, "pro")
+    assert np.all(Q[:, 1] == 0) and Q[:, 7].max() <= 0.003 and Q[:, 8].max() <= 0.01
+    assert np.array_equal(W.lhs_params(50, "full"), W.lhs_params(50, "full"))     # seeded
+    assert W.lhs_params(16, "leaf").shape == (16, 27)
+
+
+@pytest.mark.skipif(not gpu_absent, reason="only meaningful on a machine without a GPU")
+def test_compute_fails_loudly_without_gpu():
+    import SPART
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        SPART.PROSPECT_5D(SPART.LeafBiology(40, 0.01, 0.02, 0, 10, 10, 1.5), None)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        SPART.SPART(SPART.SoilParameters(0.5, 0, 100, 15, 25, 0.015), SPART.LeafBiology(40, 0.01, 0.02, 0, 10, 10, 1.5),
+                    SPART.CanopyStructure(3, -0.35, -0.15, 0.05), SPART.AtmosphericProperties(0.3, 0.3, 1.4),
+                    SPART.Angles(40, 0, 0), "Sentinel2A-MSI", 100).run()
+
+
+def test_product_never_imports_the_oracle():
+    """The shipped package must not reference oracle/ or tests/hostmath (parity rule)."""
+    import os
+    from conftest import ROOT
+    pkg = os.path.join(ROOT, "spart-python_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip")):
+                src = open(os.path.join(d, f)).read()
+                assert "spart_oracle" not in src and "hostmath" not in src.replace("tests/hostmath", ""), f

@@ -1,0 +1,100 @@
+"""The oracle (numpy restatement) against the golden vectors produced by the REAL reference
+(tests/golden/make_golden.py).  This is what pins the oracle."""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+
+def test_prospect(oracle, tables, golden):
+    g = golden["prospect"]
+    refl, tran, kchl = oracle.prospect_5d(g["leaf"], tables)
+    # closed-form E1 vs the reference's QUADPACK E1: 1.3e-8 abs on refl/tran (reference test precision is 1.5e-7)
+    assert np.nanmax(np.abs(refl - g["refl"])) < 5e-8
+    assert np.nanmax(np.abs(tran - g["tran"])) < 5e-8
+    assert rel_err(kchl, g["kChlrel"], 1e-12) < 1e-12
+    # README leaf (Cdm = 10): the reference has 11 NaNs at 400-410 nm from cancellation noise in its quadrature
+    assert np.isnan(g["refl"][13]).sum() == 11 and np.isnan(g["refl"]).sum() == 11
+
+
+def test_prospect_literal_quadrature_reproduces_nans(oracle, tables, golden):
+    g = golden["prospect"]
+    refl, tran, _ = oracle.prospect_5d(g["leaf"][13:14], tables, e1="quad")
+    assert (np.isnan(refl) == np.isnan(g["refl"][13:14])).all()
+    m = np.isfinite(refl)
+    assert np.max(np.abs(refl[m] - g["refl"][13:14][m])) < 1e-15
+    assert np.max(np.abs(tran[m] - g["tran"][13:14][m])) < 1e-15
+
+
+def test_bsm(oracle, tables, golden):
+    g = golden["bsm"]
+    wet, dry = oracle.bsm(g["soil"], tables)
+    assert rel_err(wet, g["refl"], 1e-9) < 1e-12
+    assert rel_err(dry, g["refl_dry"], 1e-9) < 1e-12
+    # SMp <= 5 rows: no moisture effect (bsm.py:101-103)
+    assert np.array_equal(g["refl"][2], g["refl_dry"][2]) and np.array_equal(g["refl"][3], g["refl_dry"][3])
+
+
+def test_leafangles(oracle, golden):
+    g = golden["sailh"]
+    lidf = oracle.calculate_leafangles(g["canopy"][:, 1], g["canopy"][:, 2])
+    assert np.max(np.abs(lidf - g["lidf"])) < 1e-15
+    assert np.allclose(lidf.sum(axis=1), 1.0)
+
+
+@pytest.mark.parametrize("pso", ["quad", "gl"])
+def test_sailh(oracle, golden, pso):
+    g = golden["sailh"]
+    n = g["canopy"].shape[0]
+    rep = lambda v: np.repeat(v[None], n, 0)
+    c = oracle.sailh(rep(g["leaf_refl"]), rep(g["leaf_tran"]), rep(g["soil_refl"]), g["canopy"], g["angles"], pso=pso)
+    for k in ("rso", "rdo", "rsd", "rdd"):
+        assert rel_err(c[k], g[k], 1e-9) < 1e-10, k
+
+
+def test_sailh_length_check(oracle):
+    with pytest.raises(RuntimeError, match="2162"):
+        oracle.sailh(np.zeros((1, 2001)), np.zeros((1, 2001)), np.zeros((1, 2001)), [[3, 0, 0, 0.05]], [[40, 0, 0]])
+
+
+@pytest.mark.parametrize("sensor", ["Sentinel2A-MSI", "Sentinel2B-MSI", "TerraAqua-MODIS", "LANDSAT7-ETM",
+                                    "LANDSAT8-OLI", "Sentinel3A-OLCI"])
+def test_smac(oracle, tables, golden, sensor):
+    g = golden["smac"]
+    out = oracle.smac(g[f"{sensor}/angles"], g[f"{sensor}/atm"], oracle.sensor_tables(tables, sensor))
+    tol = 2e-6 if sensor.startswith("Sentinel2") else 1e-12     # float32 coefficients in the S2 pickles
+    for f in oracle.SMAC_OUT:
+        assert rel_err(out[f], g[f"{sensor}/{f}"], 1e-9) < tol, f
+
+
+def test_full_chain(oracle, tables, golden):
+    g = golden["e2e"]
+    for name in sorted(set(k.rsplit("/", 1)[0] for k in g.files)):
+        sensor = name.split("/")[1]
+        o = oracle.spart_run(g[name + "/P"], sensor, tables, full=True)
+        tol = 5e-7 if sensor.startswith("Sentinel2") else 1e-10
+        for k in ("R_TOC", "R_TOA", "L_TOA", "rsoil", "La"):
+            assert rel_err(o[k], g[f"{name}/{k}"], 1e-9) < tol, (name, k)
+        probes = [0, 150, 400, 1000, 1600, 2000, 2100]
+        rho, tau = oracle.pad_leaf(o["leaf_refl"], o["leaf_tran"])
+        got = np.concatenate([rho[:, probes], tau[:, probes], oracle.pad_soil(o["soil_refl"])[:, probes],
+                              o["rso"][:, probes], o["rdo"][:, probes], o["rsd"][:, probes], o["rdd"][:, probes]], axis=1)
+        assert rel_err(got, g[name + "/probes"], 0.1) < 1e-6, name   # abs 1e-7: the reference E1 quadrature noise
+
+
+def test_known_answer_pins(oracle, tables):
+    """SURVEY.md §8(a) pins captured from the reference (defaults, Sentinel2A, DOY 100)."""
+    from spart_amd_workloads import default_row
+    o = oracle.spart_run(default_row(), "Sentinel2A-MSI", tables, full=True)
+    assert abs(o["R_TOC"][0, 0] / 0.01647096010384845 - 1) < 1e-7    # closed-form E1 vs quadrature E1
+    assert abs(o["R_TOC"][0, 5] / 0.3371841542003048 - 1) < 1e-7
+    assert abs(o["R_TOA"][0, 5] / 0.3143871040199252 - 1) < 5e-7
+    assert abs(o["L_TOA"][0, 10] / 0.00012061660603157987 - 1) < 5e-7
+    assert abs(o["leaf_refl"][0, 150] - 0.06375474885800862) < 5e-8
+    assert abs(o["soil_refl"][0, 400] - 0.3978653598241099) < 1e-12
+    assert abs(o["rdd"][0, 2100] - 0.005657296144770152) < 1e-12
+
+
+def test_unknown_sensor(oracle, tables):
+    with pytest.raises(FileNotFoundError):
+        oracle.sensor_tables(tables, "Sentinel9Z")
