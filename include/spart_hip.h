@@ -69,7 +69,8 @@ typedef struct spart_tables {
 } spart_tables;
 
 /* Optional full-spectrum outputs of spart_run_batch (the reference object's soilopt /
- * leafopt / canopyopt attributes, SPART.py:66-81).  NULL members are skipped. */
+ * leafopt / canopyopt attributes, SPART.py:66-81) and evaluation options.  NULL members are skipped;
+ * passing opt = NULL means: columns only, all bands evaluated. */
 typedef struct spart_materialize {
   void *leaf_refl, *leaf_tran; /* (B,2162) thermal-padded, SPART.py:445-470 */
   void *leaf_kchl;             /* (B,2001) kChlrel, prospect_5d.py:197-198   */
@@ -78,6 +79,10 @@ typedef struct spart_materialize {
   void *rso, *rdo, *rsd, *rdd; /* (B,2162) sailh.py:224-233                  */
   void *rsoil;                 /* (B,nb) debug column, SPART.py:262-267      */
   void *La;                    /* (B,nb) convolved ET radiance, SPART.py:183 */
+  void *band_mean;             /* (4,2162) batch means of rso, rdo, rsd, rdd (LUT summary; no reference counterpart) */
+  int32_t prune_unused_bands;  /* 0 (default): every one of the 2162 bands of every sample is evaluated and
+                                  feeds band_mean's per-chunk sums; 1: bands that no requested output needs
+                                  may be skipped (columns are identical, the work is not "full spectra") */
 } spart_materialize;
 
 int spart_ctx_create(spart_ctx **out, int device, const spart_tables *tables);

@@ -1,6 +1,6 @@
 """Build libspart_hip.so (the C-ABI library of include/spart_hip.h) in-tree with hipcc for gfx950.
 
-    python spart-python_amd/build.py [--fast-math] [--force]
+    python spart-python_amd/build.py [--force]      (SPART_FAST_MATH=0 builds the IEEE-division / libm variant)
 
 hipcc cross-compiles without a GPU.  The .so lands next to this file so that it travels with
 the source tree (it is git-ignored, not gpurun-ignored).
@@ -14,6 +14,10 @@ SRC = os.path.join(HERE, "csrc", "spart_capi.hip")
 DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("spart_kernels.h", "spart_math.h", "spart_e3_coeffs.h")] + [
     os.path.join(HERE, "..", "include", "spart_hip.h")]
 OUT = os.path.join(HERE, "libspart_hip.so")
+# -fno-slp-vectorize: hipcc's SLP pass packs independent fp32 ops into v_pk_mul/v_pk_fma, which issue at
+# half rate on gfx950 and block FMA contraction; the VALU-bound band kernel is 12 % faster without it
+# (profiles/README.md)
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-fno-slp-vectorize"]
 
 
 def hipcc():
@@ -30,12 +34,19 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in DEPS)
 
 
-def build(force=False, fast_math=None, verbose=True):
+def build(force=False, fast_math=None, verbose=True, out=None, extra=()):
+    """out / extra: build a variant (other output path, extra hipcc flags) for tools/ab_bench.py."""
+    if out is not None:
+        cmd = [hipcc(), *FLAGS, "-o", out, SRC, "-DSPART_FAST_MATH=1", *extra]
+        if verbose:
+            print("[spart_amd] " + " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        return out
     if fast_math is None:
-        fast_math = os.environ.get("SPART_FAST_MATH", "0") == "1"
+        fast_math = os.environ.get("SPART_FAST_MATH", "1") == "1"   # default: hardware rcp/exp/log/sqrt (parity-tested)
     if not force and not needs_build():
         return OUT
-    cmd = [hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-o", OUT, SRC]
+    cmd = [hipcc(), *FLAGS, "-o", OUT, SRC]
     if fast_math:
         cmd.insert(1, "-DSPART_FAST_MATH=1")
     if verbose:

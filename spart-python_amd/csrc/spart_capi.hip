@@ -71,8 +71,15 @@ struct DeviceGuard {
 inline size_t align_up(size_t x) { return (x + 255) & ~size_t(255); }
 
 struct Workspace {
-  size_t cst_off, atm_off, g_off, gs_off, total;
+  size_t cst_off, atm_off, g_off, gs_off, bs_off, total;
 };
+
+// samples per workgroup of the band kernels: ~2048 chunk rows when the batch allows it (x 8 tiles =
+// 16k workgroups over 256 CUs), so the per-chunk band sums stay <= 64 MB (fp32) whatever B is
+int pick_chunk(int64_t B) {
+  int64_t c = (B + 2047) / 2048;
+  return (int)(c < 1 ? 1 : c);
+}
 
 Workspace carve(int dtype, int64_t B, int nslot) {
   size_t es = dtype == SPART_F64 ? 8 : 4;
@@ -82,17 +89,11 @@ Workspace carve(int dtype, int64_t B, int nslot) {
   w.atm_off = o; o = align_up(o + (size_t)B * NATM * 8);
   w.g_off = o;   o = align_up(o + (size_t)B * (size_t)(nslot > 0 ? nslot : 1) * 4 * es);
   w.gs_off = o;  o = align_up(o + (size_t)B * (size_t)(nslot > 0 ? nslot : 1) * es);
+  int chunk = pick_chunk(B);
+  size_t nchunk = (size_t)((B + chunk - 1) / chunk);
+  w.bs_off = o;  o = align_up(o + nchunk * (size_t)(NTILE * TILE) * 4 * es);
   w.total = o;
   return w;
-}
-
-int pick_chunk(int64_t B) {
-  // >= ~4096 workgroups when the batch allows it (256 CUs x 8 XCD-interleaved tiles), at most
-  // 64 samples per workgroup so that the table slice in VGPRs is amortised
-  int64_t c = (B * NTILE + 4095) / 4096;
-  if (c < 1) c = 1;
-  if (c > 64) c = 64;
-  return (int)c;
 }
 
 // np.interp(x, wlS, .) support points (SPART.py:220-223) on the 2162-point grid
@@ -204,14 +205,18 @@ static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_
           mp.rdd || mp.gsoil;
   }
   dim3 grid((unsigned)(nchunk * NTILE));
+  T* bsum = (T*)(wsp + ws.bs_off);
+  const bool full = !(opt && opt->prune_unused_bands);
   const bool prof = ctx->profile && ctx->ev_used + 2 <= ctx->ev.size();
   if (prof) HIP_TRY(ctx, hipEventRecord(ctx->ev[ctx->ev_used], st));
-  if (mat)
-    hipLaunchKernelGGL((k_bands<T, true>), grid, dim3(TILE), 0, st, tab, (const T*)cst, (const int*)ctx->need_slot,
-                       ctx->nslot, G, B, chunk, mp);
-  else
-    hipLaunchKernelGGL((k_bands<T, false>), grid, dim3(TILE), 0, st, tab, (const T*)cst, (const int*)ctx->need_slot,
-                       ctx->nslot, G, B, chunk, mp);
+#define SPART_LAUNCH_BANDS(M, F)                                                                                 \
+  hipLaunchKernelGGL((k_bands<T, M, F>), grid, dim3(TILE), 0, st, tab, (const T*)cst, (const int*)ctx->need_slot, \
+                     ctx->nslot, G, B, chunk, mp, bsum)
+  if (mat && full) SPART_LAUNCH_BANDS(true, true);
+  else if (mat) SPART_LAUNCH_BANDS(true, false);
+  else if (full) SPART_LAUNCH_BANDS(false, true);
+  else SPART_LAUNCH_BANDS(false, false);
+#undef SPART_LAUNCH_BANDS
   HIP_TRY(ctx, hipGetLastError());
   if (prof) {
     HIP_TRY(ctx, hipEventRecord(ctx->ev[ctx->ev_used + 1], st));
@@ -225,6 +230,12 @@ static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_
         hipLaunchKernelGGL((k_fill_thermal<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, B);
         HIP_TRY(ctx, hipGetLastError());
       }
+  }
+  if (opt && opt->band_mean) {
+    if (!full) return fail(ctx, SPART_ERR_INVALID, "spart_run_batch: band_mean needs prune_unused_bands = 0");
+    hipLaunchKernelGGL((k_bandmean<T>), dim3((4 * NWLS + 255) / 256), dim3(256), 0, st, (const T*)bsum, nchunk, B,
+                       (T*)opt->band_mean);
+    HIP_TRY(ctx, hipGetLastError());
   }
   SensorTab stb{ctx->slot0, ctx->slot1, ctx->frac, ctx->coef, ctx->econv, ctx->nb, ctx->nslot};
   int64_t n = B * ctx->nb;

@@ -106,10 +106,17 @@ template <typename T> struct MatPtrs {
 // K2: the fused band kernel: PROSPECT + BSM + SAILH for every band of every sample.
 // grid.x = nchunk * NTILE (tile fastest), block = 256.
 // G receives rso, rdo, rsd, rdd at the bands the sensor needs: (B, nslot, 4).
-template <typename T, bool MAT>
+//
+// FULL = true (the default mode of spart_run_batch): every one of the 2002 band evaluations of every
+// sample is observable -- each lane accumulates its band's four canopy reflectances over the chunk and
+// writes the sums to bandsum[chunk][2048][4] (reduced to batch-mean spectra by k_bandmean on request).
+// Without that the compiler legally sinks most of the soil / canopy arithmetic into the
+// `slot >= 0` store and skips it for the waves that hold no sensor band; that behaviour is the explicit
+// opt-in FULL = false ("prune_unused_bands").
+template <typename T, bool MAT, bool FULL>
 __global__ __launch_bounds__(TILE) void k_bands(const T* __restrict__ tab, const T* __restrict__ cst,
                                                 const int* __restrict__ need_slot, int nslot, T* __restrict__ G,
-                                                int64_t B, int chunk, MatPtrs<T> mat) {
+                                                int64_t B, int chunk, MatPtrs<T> mat, T* __restrict__ bandsum) {
   const int tile = blockIdx.x % NTILE;
   const int64_t ck = blockIdx.x / NTILE;
   const int band = tile * TILE + threadIdx.x;          // 0..2047
@@ -120,6 +127,7 @@ __global__ __launch_bounds__(TILE) void k_bands(const T* __restrict__ tab, const
   const int slot = active ? need_slot[band] : -1;
   const int64_t s0 = ck * chunk;
   const int64_t s1 = (s0 + chunk < B) ? s0 + chunk : B;
+  T sum_so = T(0), sum_do = T(0), sum_sd = T(0), sum_dd = T(0);
   for (int64_t s = s0; s < s1; ++s) {
     const T* __restrict__ c = cst + s * NCONST;        // wave-uniform -> scalar loads
     T refl, tran, absb, K;
@@ -128,13 +136,16 @@ __global__ __launch_bounds__(TILE) void k_bands(const T* __restrict__ tab, const
     T rdry = soil_dry<T>(tb, c[C_F1], c[C_F2], c[C_F3]);
     T fm[7] = {c[C_FM0], c[C_FM1], c[C_FM2], c[C_FM3], c[C_FM4], c[C_FM5], c[C_FM6]};
     T rwet;
-    soil_band<T>(tb, rdry, c[C_WET], fm, c[C_FILM2], rwet);
+    soil_band<T>(tb, rdry, c[C_WET], fm, c[C_FMSUM], c[C_FILM2], rwet);
     T rho = thermal ? c[C_RHO_TH] : refl;              // SPART.py:463-466
     T tau = thermal ? c[C_TAU_TH] : tran;
     T ab = thermal ? (T(1) - c[C_RHO_TH] - c[C_TAU_TH]) : absb;
     const CanopyPar<T> cp = load_canopy(c);
     T rso, rdo, rsd, rdd;
     canopy_band<T>(cp, rho, tau, ab, rwet, rso, rdo, rsd, rdd);
+    if (FULL) {
+      sum_so += rso; sum_do += rdo; sum_sd += rsd; sum_dd += rdd;
+    }
     if (slot >= 0) {
       T* g = G + (s * nslot + slot) * 4;
       g[0] = rso; g[1] = rdo; g[2] = rsd; g[3] = rdd;
@@ -158,6 +169,23 @@ __global__ __launch_bounds__(TILE) void k_bands(const T* __restrict__ tab, const
       }
     }
   }
+  if (FULL) {
+    T* bs = bandsum + (ck * (NTILE * TILE) + band) * 4;
+    bs[0] = sum_so; bs[1] = sum_do; bs[2] = sum_sd; bs[3] = sum_dd;
+  }
+}
+
+// batch-mean canopy spectra from the per-chunk band sums: out (4, 2162) = mean over samples of rso, rdo, rsd, rdd
+template <typename T>
+__global__ __launch_bounds__(256) void k_bandmean(const T* __restrict__ bandsum, int64_t nchunk, int64_t B,
+                                                  T* __restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;   // 0 .. 4*2162-1
+  if (i >= 4 * NWLS) return;
+  int q = i / NWLS, band = i % NWLS;
+  int ev = band < NWL ? band : NWL;                // thermal bands share evaluation 2001
+  double acc = 0.0;
+  for (int64_t c = 0; c < nchunk; ++c) acc += (double)bandsum[(c * (NTILE * TILE) + ev) * 4 + q];
+  out[i] = (T)(acc / (double)B);
 }
 
 // copy the thermal evaluation (position 2001) over the other 160 thermal bands
@@ -214,7 +242,7 @@ __global__ __launch_bounds__(TILE) void k_bsm(const T* __restrict__ tab, const T
     T rdry = rdry_in ? (active ? rdry_in[s * NWL + band] : T(0)) : soil_dry<T>(tb, c[C_F1], c[C_F2], c[C_F3]);
     T fm[7] = {c[C_FM0], c[C_FM1], c[C_FM2], c[C_FM3], c[C_FM4], c[C_FM5], c[C_FM6]};
     T rwet;
-    soil_band<T>(tb, rdry, c[C_WET], fm, c[C_FILM2], rwet);
+    soil_band<T>(tb, rdry, c[C_WET], fm, c[C_FMSUM], c[C_FILM2], rwet);
     if (active) {
       const int64_t o = s * NWL + band;
       if (o_refl) o_refl[o] = rwet;

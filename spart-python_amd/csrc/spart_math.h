@@ -62,7 +62,7 @@ template <> struct Mx<float> {
   }
   static SPART_HD float log(float x) {
 #if defined(__HIP_DEVICE_COMPILE__) && defined(SPART_FAST_MATH)
-    return __logf(x);
+    return __builtin_amdgcn_logf(x) * 0.693147181f;   // v_log_f32 (log2), arguments here are normal floats
 #else
     return ::logf(x);
 #endif
@@ -81,7 +81,27 @@ template <> struct Mx<float> {
     return 1.0f / x;
 #endif
   }
-  static SPART_HD float log1p(float x) { return ::log1pf(x); }
+  // log1p for x >= 0 (the only use: ln b, b >= 1): 2 atanh(x/(2+x)) series below 0.5, log(1+x) above
+  static SPART_HD float log1p(float x) {
+#if defined(SPART_FAST_MATH)
+    float s = x * rcp(2.0f + x);
+    float s2 = s * s;
+    float p = 2.0f * s * (1.0f + s2 * (0.333333333f + s2 * (0.2f + s2 * (0.142857143f + s2 * 0.111111111f))));
+    return (x < 0.5f) ? p : log(1.0f + x);
+#else
+    return ::log1pf(x);
+#endif
+  }
+  // 1 - e^-z for z >= 0 without cancellation: Taylor below 0.25 (z^8/8! = 3.8e-10), direct above
+  static SPART_HD float one_minus_exp_neg(float z) {
+#if defined(SPART_FAST_MATH)
+    float p = z * (1.0f + z * (-0.5f + z * (0.166666667f + z * (-0.0416666667f + z * (8.33333333e-3f +
+              z * (-1.38888889e-3f + z * 1.98412698e-4f))))));
+    return (z < 0.25f) ? p : 1.0f - exp(-z);
+#else
+    return -::expm1f(-z);
+#endif
+  }
   static SPART_HD float expm1(float x) { return ::expm1f(x); }
   static SPART_HD float fabs(float x) { return ::fabsf(x); }
   static SPART_HD float fmax(float a, float b) { return ::fmaxf(a, b); }
@@ -95,6 +115,7 @@ template <> struct Mx<double> {
   static SPART_HD double sqrt(double x) { return ::sqrt(x); }
   static SPART_HD double rcp(double x) { return 1.0 / x; }
   static SPART_HD double log1p(double x) { return ::log1p(x); }
+  static SPART_HD double one_minus_exp_neg(double z) { return -::expm1(-z); }
   static SPART_HD double expm1(double x) { return ::expm1(x); }
   static SPART_HD double fabs(double x) { return ::fabs(x); }
   static SPART_HD double fmax(double a, double b) { return ::fmax(a, b); }
@@ -111,6 +132,31 @@ template <typename T> SPART_HD T phi_fn(T d) {
   T v = -Mx<T>::expm1(-safe) * Mx<T>::rcp(safe);
   return (Mx<T>::fabs(d) < small) ? (T(1) - T(0.5) * d) : v;
 }
+
+// SAIL J-functions (sailh.py:154-183) for x = -1 / x = 0:
+//   J1 = (e^-mL - e^-kL)/(k - m) = L e^-kL phi((m-k)L),   J2 = (1 - e^-kL e^-mL)/(k + m) = L phi((k+m)L)
+// float shares e1 = exp(-m L) between the four of them and switches to the Taylor polynomial of phi
+// for |d| < 0.06 (next term d^5/720 = 1e-9), so no difference of nearly equal exponentials is formed;
+// double goes through expm1.
+template <typename T> struct SailJ;
+template <> struct SailJ<float> {
+  static SPART_HD float poly(float d) {
+    return 1.0f + d * (-0.5f + d * (0.166666667f + d * (-0.0416666667f + d * 8.33333333e-3f)));
+  }
+  static SPART_HD float j1(float L, float tk, float e1, float d) {  // d = (m - k) L, tk = e^-kL
+    if (::fabsf(d) < 0.06f) return L * tk * poly(d);
+    return L * (tk - e1) * Mx<float>::rcp(d);
+  }
+  static SPART_HD float j2(float L, float tk, float e1, float kpm, float ikpm) {  // kpm = k + m > 0, ikpm = 1/kpm
+    float d = kpm * L;
+    float v = (1.0f - tk * e1) * ikpm;
+    return (d < 0.06f) ? L * poly(d) : v;
+  }
+};
+template <> struct SailJ<double> {
+  static SPART_HD double j1(double L, double tk, double, double d) { return L * tk * phi_fn(d); }
+  static SPART_HD double j2(double L, double, double, double kpm, double) { return L * phi_fn(kpm * L); }
+};
 
 // ------------------------------------------------------------------------------------------
 // tau(K) = (1-K) exp(-K) + K^2 E1(K) = 2 E3(K)           (prospect_5d.py:183-196)
@@ -131,30 +177,30 @@ template <> struct E3c<double> {
 
 template <typename T> SPART_HD void plate_tau(T K, T& tau, T& u) {
   using C = E3c<T>;
-  // small branch, evaluated at min(K,1)
-  T xs = Mx<T>::fmin(Mx<T>::fmax(K, Mx<T>::tiny()), T(1));
-  T g = C::g(C::GD);
+  // K <= 0 (and NaN, as in the reference where only Kall > 0 entries are replaced, prospect_5d.py:182,195)
+  // is clamped to a tiny positive value: tau -> 1, u -> 0+, and the Stokes terms below reach the
+  // reference's zero-absorption limit (prospect_5d.py:233-235) continuously.
+  T x = Mx<T>::fmax(K, Mx<T>::tiny());
+  const bool small = x < T(1);
+  T v;  // u on the small branch, tau on the large one (one value, so nothing is spilled to select them)
+  if (small) {
+    T g = C::g(C::GD);
 #pragma unroll
-  for (int i = C::GD - 1; i >= 0; --i) g = g * xs + C::g(i);
-  T us = xs * (g + xs * Mx<T>::log(xs));
-  // large branch, evaluated at t = 1/max(K,1)
-  T xl = Mx<T>::fmax(K, T(1));
-  T t = Mx<T>::rcp(xl);
-  T pn = C::p(C::WD), qn = C::q(C::WD);
+    for (int i = C::GD - 1; i >= 0; --i) g = g * x + C::g(i);
+    v = x * (g + x * Mx<T>::log(x));
+  } else {
+    T t = Mx<T>::rcp(x);
+    T pn = C::p(C::WD), qn = C::q(C::WD);
 #pragma unroll
-  for (int i = C::WD - 1; i >= 0; --i) {
-    pn = pn * t + C::p(i);
-    qn = qn * t + C::q(i);
+    for (int i = C::WD - 1; i >= 0; --i) {
+      pn = pn * t + C::p(i);
+      qn = qn * t + C::q(i);
+    }
+    v = Mx<T>::exp(-x) * (T(2) * t) * pn * Mx<T>::rcp((T(1) + T(3) * t) * qn);
   }
-  T tl = Mx<T>::exp(-xl) * (T(2) * t) * pn * Mx<T>::rcp((T(1) + T(3) * t) * qn);
-  bool small = K < T(1);
-  u = small ? us : (T(1) - tl);
-  tau = small ? (T(1) - us) : tl;
-  if (!(K > T(0))) {  // K <= 0 (NaN stays NaN through the arithmetic above)
-    bool isnan_ = (K != K);
-    tau = isnan_ ? K : T(1);
-    u = isnan_ ? K : T(0);
-  }
+  T w = T(1) - v;
+  u = small ? v : w;
+  tau = small ? w : v;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -207,7 +253,7 @@ enum ConstIdx {
   // canopy (sailh.py:93-105, 200-203, 216, 219)
   C_SDB, C_SDF, C_DDB, C_DDF, C_DOB, C_DOF, C_SOB, C_SOF, C_BF, C_KS, C_KO, C_LAI,
   C_TSS, C_TOO, C_Z, C_HOT, C_PSO2W,
-  C_RSV0, C_RSV1, C_RSV2, C_RSV3, C_RSV4, C_RSV5, C_RSV6, C_RSV7,
+  C_FMSUM, C_RSV1, C_RSV2, C_RSV3, C_RSV4, C_RSV5, C_RSV6, C_RSV7,
   NCONST  // 48
 };
 static_assert(NCONST == 48, "constant block is 48 values");
@@ -249,20 +295,15 @@ SPART_HD void leaf_band(const BandTab<T>& tb, T cab, T cca, T cdm, T cw, T cs, T
   T a = T(1) + am1;
   T z = nm1 * Mx<T>::log1p(bm1);  // (N-1) ln b
   T sq = Mx<T>::exp(-z);          // b^-(N-1)
-  T omsq = -Mx<T>::expm1(-z);     // 1 - b^-(N-1)
+  T omsq = Mx<T>::one_minus_exp_neg(z);  // 1 - b^-(N-1)
   T omq = omsq * (T(1) + sq);     // 1 - b^-2(N-1)
   T A2 = am1 * (a + T(1));        // a^2 - 1
   T iden = Mx<T>::rcp(A2 + omq);  // b^-2(N-1) (a^2 b^2(N-1) - 1)
   T Rsub = a * omq * iden;        // :229
   T Tsub = sq * A2 * iden;        // :230
   T asub = am1 * omsq * (a - sq) * iden;  // 1 - Rsub - Tsub
-  if (!(a1 > T(0))) {             // zero absorption, r + t >= 1 (:233-235)
-    T tz = divx(t, t + (T(1) - t) * nm1);
-    bool nanv = (a1 != a1);
-    Tsub = nanv ? a1 : tz;
-    Rsub = nanv ? a1 : (T(1) - tz);
-    asub = nanv ? a1 : T(0);
-  }
+  // zero absorption (r + t >= 1, :233-235) is the a1 -> 0+ limit of the expressions above:
+  // Tsub -> t/(t + (1-t)(N-1)), Rsub -> 1 - Tsub; plate_tau keeps a1 > 0 so no branch is needed.
   T dd = Mx<T>::rcp(T(1) - Rsub * r);  // :239
   tran = Ta * Tsub * dd;               // :240
   refl = Ra + Ta * Rsub * t * dd;      // :241
@@ -272,20 +313,19 @@ SPART_HD void leaf_band(const BandTab<T>& tb, T cab, T cca, T cdm, T cw, T cs, T
 // ------------------------------------------------------------------------------------------
 // BSM + soilwat, one band                                        (bsm.py:49-52, 99-124)
 template <typename T>
-SPART_HD void soil_band(const BandTab<T>& tb, T rdry, T wet, const T fm[7], T film2, T& rwet) {
+SPART_HD void soil_band(const BandTab<T>& tb, T rdry, T wet, const T fm[7], T fmsum16, T film2, T& rwet) {
   T rbac = T(1) - (T(1) - rdry) * (rdry * tb.cbac + T(1) - rdry);  // :110-112
   T tw1 = Mx<T>::exp(-film2 * tb.kw);                              // :122 with k = 1
-  T tw = T(1);
-  T acc = rdry * fm[0];                                            // :124
-  T c1 = (T(1) - tb.rw) * (T(1) - tb.pw);
+  // rwet = rdry f0 + sum_k f_k [Rw + (1-Rw)(1-p) x_k/(1 - p x_k)],  x_k = tw1^k rbac   (:123-124)
+  T x = rbac;
+  T acc = T(0);
 #pragma unroll
   for (int k = 1; k <= 6; ++k) {
-    tw *= tw1;
-    T x = tw * rbac;
-    T Rk = tb.rw + c1 * x * Mx<T>::rcp(T(1) - tb.pw * x);          // :123
-    acc += Rk * fm[k];
+    x *= tw1;
+    acc += fm[k] * x * Mx<T>::rcp(T(1) - tb.pw * x);
   }
-  rwet = (wet > T(0)) ? acc : rdry;                                // :102-103
+  T v = rdry * fm[0] + tb.rw * fmsum16 + (T(1) - tb.rw) * (T(1) - tb.pw) * acc;
+  rwet = (wet > T(0)) ? v : rdry;                                  // :102-103
 }
 
 template <typename T> SPART_HD T soil_dry(const BandTab<T>& tb, T f1, T f2, T f3) {
@@ -314,30 +354,31 @@ SPART_HD void canopy_band(const CanopyPar<T>& c, T rho, T tau, T absb, T rs, T& 
   T rinf2 = rinf * rinf;
   T L = c.lai;
   // J1(-1) = (e^-mL - e^-kL)/(k - m) = L e^-kL phi((m-k)L)   (:154-170, 180-183)
-  T J1k = L * c.tss * phi_fn((m - c.ks) * L);
-  T J1K = L * c.too * phi_fn((m - c.ko) * L);
-  // J2(0) = (1 - e^-kL e^-mL)/(k + m) = L phi((k+m)L)        (:172-177)
-  T J2k = L * phi_fn((c.ks + m) * L);
-  T J2K = L * phi_fn((c.ko + m) * L);
   T e1 = Mx<T>::exp(-m * L);           // :185-189
+  T J1k = SailJ<T>::j1(L, c.tss, e1, (m - c.ks) * L);
+  T J1K = SailJ<T>::j1(L, c.too, e1, (m - c.ko) * L);
+  // J2(0) = (1 - e^-kL e^-mL)/(k + m) = L phi((k+m)L)        (:172-177)
+  T iks = Mx<T>::rcp(c.ks + m), iko = Mx<T>::rcp(c.ko + m);
+  T J2k = SailJ<T>::j2(L, c.tss, e1, c.ks + m, iks);
+  T J2K = SailJ<T>::j2(L, c.too, e1, c.ko + m, iko);
   T e2 = e1 * e1;
   T re = rinf * e1;
-  T iden = Mx<T>::rcp(T(1) - rinf2 * rinf2);  // sic: 1 - rinf2**2 (:189)
+  T i1 = Mx<T>::rcp(T(1) - rinf2 * rinf2);  // sic: 1 - rinf2**2 (:189)
+  T i2 = (T(1) + rinf2) * i1;                // 1/(1 - rinf2)  (:214)
   T s1 = sf + rinf * sb;               // :191-198
   T s2 = sf * rinf + sb;
   T v1 = vf + rinf * vb;
   T v2 = vf * rinf + vb;
   T Pss = s1 * J1k, Qss = s2 * J2k, Poo = v1 * J1K, Qoo = v2 * J2K;
-  T tau_dd = (T(1) - rinf2) * e1 * iden;  // :205-210
-  T rho_dd = rinf * (T(1) - e2) * iden;
-  T tau_sd = (Pss - re * Qss) * iden;
-  T tau_do = (Poo - re * Qoo) * iden;
-  T rho_sd = (Qss - re * Pss) * iden;
-  T rho_do = (Qoo - re * Poo) * iden;
-  T T1 = v2 * s1 * (c.Z - J1k * c.too) * Mx<T>::rcp(c.ko + m) +
-         v1 * s2 * (c.Z - J1K * c.tss) * Mx<T>::rcp(c.ks + m);  // :212
-  T T2 = -(Qoo * rho_sd + Poo * tau_sd) * rinf;                   // :213
-  T rho_sod = (T1 + T2) * Mx<T>::rcp(T(1) - rinf2);               // :214
+  T tau_dd = (T(1) - rinf2) * e1 * i1;  // :205-210
+  T rho_dd = rinf * (T(1) - e2) * i1;
+  T tau_sd = (Pss - re * Qss) * i1;
+  T tau_do = (Poo - re * Qoo) * i1;
+  T rho_sd = (Qss - re * Pss) * i1;
+  T rho_do = (Qoo - re * Poo) * i1;
+  T T1 = v2 * s1 * (c.Z - J1k * c.too) * iko + v1 * s2 * (c.Z - J1K * c.tss) * iks;  // :212
+  T T2 = -(Qoo * rho_sd + Poo * tau_sd) * rinf;                                      // :213
+  T rho_sod = (T1 + T2) * i2;                                                        // :214
   T rho_so = rho_sod + w * c.hot;                                 // :216-217
   T idn = Mx<T>::rcp(T(1) - rs * rho_dd);                         // :222
   rso = rho_so + rs * c.pso2w +
@@ -510,14 +551,17 @@ SPART_HD void sample_prelude(const double* p /*[27]*/, double rho_th, double tau
   bool wet = mu > 0.0;
   cst[C_WET] = T(wet ? 1.0 : 0.0);
   {
-    double e = wet ? ::exp(-mu) : 1.0, pw = 1.0, fact = 1.0;
+    double e = wet ? ::exp(-mu) : 1.0, pw = 1.0, fact = 1.0, fsum = 0.0;
     for (int k = 0; k < 7; ++k) {  // poisson.pmf(k, mu) = e^-mu mu^k / k!
       if (k > 0) {
         pw *= mu;
         fact *= k;
       }
-      cst[C_FM0 + k] = T(wet ? e * pw / fact : (k == 0 ? 1.0 : 0.0));
+      double f = wet ? e * pw / fact : (k == 0 ? 1.0 : 0.0);
+      cst[C_FM0 + k] = T(f);
+      if (k > 0) fsum += f;
     }
+    cst[C_FMSUM] = T(fsum);
   }
   cst[C_FILM2] = T(2.0 * film);
   }

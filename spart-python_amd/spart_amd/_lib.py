@@ -21,7 +21,7 @@ class SpartTables(ctypes.Structure):
 
 class SpartMaterialize(ctypes.Structure):
     _fields_ = [(n, vp) for n in ("leaf_refl", "leaf_tran", "leaf_kchl", "soil_refl", "soil_refl_dry", "rso", "rdo",
-                                  "rsd", "rdd", "rsoil", "La")]
+                                  "rsd", "rdd", "rsoil", "La", "band_mean")] + [("prune_unused_bands", ctypes.c_int32)]
 
 
 # name -> (restype, argtypes): every symbol include/spart_hip.h declares
@@ -47,27 +47,28 @@ SIGNATURES = {
     "spart_profile_read": (ctypes.c_int, [vp, c_dp, ctypes.POINTER(ctypes.c_int)]),
 }
 
-_lib = None
+_libs = {}
 
 
-def load():
+def load(path=None):
     """dlopen the library (torch is imported first so that its HIP runtime, soname
-    libamdhip64.so.7, is the one both sides use)."""
-    global _lib
-    if _lib is not None:
-        return _lib
+    libamdhip64.so.7, is the one both sides use).  ``path`` selects another build of the same
+    ABI (tools/ab_bench.py compares kernel variants in one process)."""
+    path = os.path.abspath(path or os.environ.get("SPART_HIP_LIB") or LIB_PATH)
+    if path in _libs:
+        return _libs[path]
     import torch  # noqa: F401
 
-    if not os.path.exists(LIB_PATH):
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"{LIB_PATH} is missing: build it with `python spart-python_amd/build.py` "
+            f"{path} is missing: build it with `python spart-python_amd/build.py` "
             "(hipcc, gfx950). spart_amd has no CPU fallback.")
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
+    _libs[path] = lib
     return lib
 
 

@@ -11,7 +11,7 @@ DTYPES = {"float32": _lib.SPART_F32, "fp32": _lib.SPART_F32, "f32": _lib.SPART_F
           "float64": _lib.SPART_F64, "fp64": _lib.SPART_F64, "f64": _lib.SPART_F64}
 SMAC_FIELDS = ["Ta_s", "Ta_o", "Tg", "Ra_dd", "Ra_so", "Ta_ss", "Ta_sd", "Ta_oo", "Ta_do"]   # smac.py:209-211
 MATERIALIZE_FIELDS = ["leaf_refl", "leaf_tran", "leaf_kchl", "soil_refl", "soil_refl_dry", "rso", "rdo", "rsd",
-                      "rdd", "rsoil", "La"]
+                      "rdd", "rsoil", "La", "band_mean"]
 _MAT_WIDTH = dict(leaf_refl=_lib.NWLS, leaf_tran=_lib.NWLS, leaf_kchl=_lib.NWL, soil_refl=_lib.NWLS,
                   soil_refl_dry=_lib.NWL, rso=_lib.NWLS, rdo=_lib.NWLS, rsd=_lib.NWLS, rdd=_lib.NWLS)
 
@@ -28,9 +28,9 @@ def _dp(a):
 
 
 class Engine:
-    def __init__(self, sensor=None, device=0, sensor_info=None):
+    def __init__(self, sensor=None, device=0, sensor_info=None, lib_path=None):
         torch = _require_gpu()
-        self.lib = _lib.load()
+        self.lib = _lib.load(lib_path)
         self.torch = torch
         self.device = torch.device("cuda", device)
         self.sensor = sensor
@@ -191,13 +191,16 @@ class Engine:
         _lib.check(self.lib, self.ctx, rc)
         return dict(zip(SMAC_FIELDS, out))
 
-    def run(self, params, dtype="float32", rho_thermal=None, tau_thermal=None, materialize=(), out=None):
+    def run(self, params, dtype="float32", rho_thermal=None, tau_thermal=None, materialize=(), out=None,
+            prune=False):
         """SPART(...).run() for every column of ``params`` (SPART.py:162-269).
 
         params : (27, B) float64 device tensor (rows = spart_amd.workloads.PARAM_NAMES) or a list of 27
                  scalars / arrays.
         materialize : iterable of names from MATERIALIZE_FIELDS to also return (full spectra etc.)
         out : optional dict with preallocated 'R_TOC','R_TOA','L_TOA' (B,nb) tensors
+        prune : False (default) evaluates all 2162 bands of every sample; True lets the kernel skip bands
+                that no requested output needs (identical columns, much less work)
         """
         torch = self.torch
         dt = DTYPES[dtype]
@@ -216,13 +219,14 @@ class Engine:
             if k not in res:
                 res[k] = torch.empty((B, self.nb), dtype=td, device=self.device)
         mat = None
-        if materialize:
+        if materialize or prune:
             mat = _lib.SpartMaterialize()
+            mat.prune_unused_bands = 1 if prune else 0
             for name in materialize:
                 if name not in MATERIALIZE_FIELDS:
                     raise ValueError(f"unknown materialize field {name}")
-                width = _MAT_WIDTH.get(name, self.nb)
-                res[name] = torch.empty((B, width), dtype=td, device=self.device)
+                shape = (4, _lib.NWLS) if name == "band_mean" else (B, _MAT_WIDTH.get(name, self.nb))
+                res[name] = torch.empty(shape, dtype=td, device=self.device)
                 setattr(mat, name, res[name].data_ptr())
         ws, wsn = self._workspace(dt, B)
         rc = self.lib.spart_run_batch(self.ctx, dt, B, self._ptrs(cols), th[0].data_ptr() if th[0] is not None else None,

@@ -41,7 +41,7 @@ static void bands_impl(int64_t B, const double* tab, const double* P, double* ou
       T rdry = soil_dry<T>(tb, c[C_F1], c[C_F2], c[C_F3]);
       T fm[7] = {c[C_FM0], c[C_FM1], c[C_FM2], c[C_FM3], c[C_FM4], c[C_FM5], c[C_FM6]};
       T rwet;
-      soil_band<T>(tb, rdry, c[C_WET], fm, c[C_FILM2], rwet);
+      soil_band<T>(tb, rdry, c[C_WET], fm, c[C_FMSUM], c[C_FILM2], rwet);
       T rho = thermal ? c[C_RHO_TH] : refl, tau = thermal ? c[C_TAU_TH] : tran;
       T ab = thermal ? (T(1) - c[C_RHO_TH] - c[C_TAU_TH]) : absb;
       T rso, rdo, rsd, rdd;

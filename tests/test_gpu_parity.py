@@ -202,3 +202,23 @@ def test_reference_style_api(golden, torch_mod, capsys):
     assert rad.rso.shape == (2162, 1)
     assert abs(rad.rso[400, 0] - 0.40396347479496547) < 1e-6 and abs(rad.rdd[2100, 0] - 0.005657296144770152) < 1e-6
     assert abs(canopy.lidf[0, 0] - 0.037891833294514) < 1e-12
+
+
+def test_all_bands_are_evaluated_and_prune_is_equivalent(oracle, tables, torch_mod):
+    """Default mode: every band of every sample feeds the per-chunk band sums -> batch-mean canopy spectra
+    must equal the oracle's means over all 2162 bands.  prune=True must give bit-identical columns."""
+    from spart_amd import get_engine, workloads
+    B = 300
+    P = workloads.lhs_params(B, "full", seed=21)
+    ref = oracle.spart_run(P, "Sentinel2A-MSI", tables, pso="gl", full=True)
+    eng = get_engine("Sentinel2A-MSI", 0)
+    Pd = torch_mod.as_tensor(P.T.copy(), device="cuda:0")
+    for dtype in ("float64", "float32"):
+        out = eng.run(Pd, dtype, materialize=("band_mean",))
+        bm = out["band_mean"].cpu().numpy()
+        for q, k in enumerate(("rso", "rdo", "rsd", "rdd")):
+            assert rel_err(bm[q], ref[k].mean(axis=0), 1e-3) < (1e-9 if dtype == "float64" else 2e-5), (dtype, k)
+        cols = {k: out[k].clone() for k in ("R_TOC", "R_TOA", "L_TOA")}
+        pr = eng.run(Pd, dtype, prune=True)
+        for k in cols:
+            assert torch_mod.equal(cols[k], pr[k]), (dtype, k)
