@@ -30,6 +30,20 @@ def algorithmic_bytes(nb, dtype):
     return 27 * 8 + 3 * nb * es
 
 
+def measured_traffic(kernel):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r1_b_traffic.json; FETCH_SIZE and WRITE_SIZE need separate passes, so this cannot be
+    collected live).  None when the profile does not cover this kernel / batch."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r1_b_traffic.json")))
+        for k, v in d.items():
+            if k.replace(" ", "") == "spart::" + kernel.replace(" ", ""):
+                return v["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(sensor, rows, seed):
     """The oracle (numpy port of the reference) timed on this box's host, bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -85,7 +99,7 @@ def main():
     gather_list = [torch.empty_like(res) for _ in range(world)] if (world > 1 and rank == 0) else None
 
     def step():
-        eng.run(P, args.dtype, out=out)
+        eng.run(P, args.dtype, out=out)       # opt = NULL: all 2162 bands of every spectrum are evaluated
         if world > 1:
             dist.gather(res, gather_list, dst=0)
 
@@ -128,8 +142,9 @@ def main():
                        "parallelism": f"dp{world} (independent shards + one RCCL gather to rank 0)" if world > 1 else "single GPU",
                        "input_dtype": "f64", "finite": ok},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_bands<float,false>" if args.dtype == "float32" else "k_bands<double,false>",
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": measured_traffic("k_bands<float,false,true>") if (args.dtype == "float32" and B == 1_000_000 and args.sensor == "Sentinel2A-MSI") else None,
+                         "kernel": "k_bands<float,false,true>" if args.dtype == "float32" else "k_bands<double,false,true>",
                          "kernel_ms": kern_s * 1e3, "algorithmic_bytes_per_spectrum": algorithmic_bytes(nb, args.dtype),
                          "note": "fused path is VALU/transcendental bound by design (SURVEY.md §8d); HBM fraction is "
                                  "reported because the metric asks for it",

@@ -133,7 +133,7 @@ static int prospect_impl(spart_ctx* ctx, int64_t B, const double* const leaf[9],
   int chunk = pick_chunk(B);
   int64_t nchunk = (B + chunk - 1) / chunk;
   const T* tab = sizeof(T) == 4 ? (const T*)ctx->tabF : (const T*)ctx->tabD;
-  hipLaunchKernelGGL((k_prospect<T>), dim3((unsigned)(nchunk * NTILE)), dim3(TILE), 0, st, tab, (const T*)cst, B, chunk,
+  hipLaunchKernelGGL((k_prospect<T>), dim3(xcd_grid(nchunk)), dim3(TILE), 0, st, tab, (const T*)cst, B, chunk,
                      (T*)refl, (T*)tran, (T*)kchl);
   HIP_TRY(ctx, hipGetLastError());
   return SPART_OK;
@@ -151,7 +151,7 @@ static int bsm_impl(spart_ctx* ctx, int64_t B, const double* const soil[6], cons
   int chunk = pick_chunk(B);
   int64_t nchunk = (B + chunk - 1) / chunk;
   const T* tab = sizeof(T) == 4 ? (const T*)ctx->tabF : (const T*)ctx->tabD;
-  hipLaunchKernelGGL((k_bsm<T>), dim3((unsigned)(nchunk * NTILE)), dim3(TILE), 0, st, tab, (const T*)cst, B, chunk,
+  hipLaunchKernelGGL((k_bsm<T>), dim3(xcd_grid(nchunk)), dim3(TILE), 0, st, tab, (const T*)cst, B, chunk,
                      (const T*)rdry_in, (T*)refl, (T*)dry);
   HIP_TRY(ctx, hipGetLastError());
   return SPART_OK;
@@ -204,7 +204,7 @@ static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_
     mat = mp.leaf_refl || mp.leaf_tran || mp.leaf_kchl || mp.soil_refl || mp.soil_dry || mp.rso || mp.rdo || mp.rsd ||
           mp.rdd || mp.gsoil;
   }
-  dim3 grid((unsigned)(nchunk * NTILE));
+  dim3 grid(xcd_grid(nchunk));
   T* bsum = (T*)(wsp + ws.bs_off);
   const bool full = !(opt && opt->prune_unused_bands);
   const bool prof = ctx->profile && ctx->ev_used + 2 <= ctx->ev.size();

@@ -18,6 +18,17 @@ constexpr int NTILE = 8;                  // 8 * 256 = 2048 >= NEVAL
 constexpr int NTILE_FULL = 9;             // 9 * 256 >= 2162 (standalone SAILH: arbitrary thermal inputs)
 constexpr int MAX_NB = 64;
 
+// XCD-aware blockIdx -> (chunk, tile) map (cdna guide T1).  Workgroups are dealt round-robin over the 8
+// XCDs, so blocks b and b + 8 share an XCD (a speed assumption only).  Within each group of 64 consecutive
+// blocks the 8 tiles of one chunk get ids {x, x+8, ..., x+56}: they land on ONE XCD and read the chunk's
+// per-sample constants through that XCD's L2 once, instead of once per XCD (8x the HBM fetches).
+// Grids are padded to a multiple of 64 blocks; padded chunks (ck >= nchunk) exit.
+__device__ __forceinline__ void xcd_map(unsigned b, int& tile, int64_t& ck) {
+  tile = (int)((b >> 3) & 7u);
+  ck = (int64_t)(b >> 6) * 8 + (b & 7u);
+}
+inline unsigned xcd_grid(int64_t nchunk) { return (unsigned)(((nchunk + 7) / 8) * 64); }
+
 struct ParamPtrs {
   const double* p[NPARAM];
   const double* rho_th;
@@ -39,7 +50,7 @@ __global__ __launch_bounds__(256) void k_prelude(ParamPtrs pp, int mask, int64_t
   T c[NCONST];
   double a[NATM];
   double li[NLINCL];
-  sample_prelude<T>(p, rho_th, tau_th, mask, c, a, li);
+  sample_prelude<T, (sizeof(T) == 4)>(p, rho_th, tau_th, mask, c, a, li);
   // constants: 48 values per sample (written once, read by 8 workgroups through s_load)
   T* dst = cst + s * NCONST;
 #pragma unroll
@@ -117,8 +128,10 @@ template <typename T, bool MAT, bool FULL>
 __global__ __launch_bounds__(TILE) void k_bands(const T* __restrict__ tab, const T* __restrict__ cst,
                                                 const int* __restrict__ need_slot, int nslot, T* __restrict__ G,
                                                 int64_t B, int chunk, MatPtrs<T> mat, T* __restrict__ bandsum) {
-  const int tile = blockIdx.x % NTILE;
-  const int64_t ck = blockIdx.x / NTILE;
+  int tile;
+  int64_t ck;
+  xcd_map(blockIdx.x, tile, ck);
+  if (ck * chunk >= B) return;
   const int band = tile * TILE + threadIdx.x;          // 0..2047
   const bool active = band < NEVAL;
   const bool thermal = band == NWL;                    // the single thermal evaluation
@@ -204,8 +217,10 @@ template <typename T>
 __global__ __launch_bounds__(TILE) void k_prospect(const T* __restrict__ tab, const T* __restrict__ cst, int64_t B,
                                                    int chunk, T* __restrict__ o_refl, T* __restrict__ o_tran,
                                                    T* __restrict__ o_kchl) {
-  const int tile = blockIdx.x % NTILE;
-  const int64_t ck = blockIdx.x / NTILE;
+  int tile;
+  int64_t ck;
+  xcd_map(blockIdx.x, tile, ck);
+  if (ck * chunk >= B) return;
   const int band = tile * TILE + threadIdx.x;
   const bool active = band < NWL;
   const BandTab<T> tb = load_tab(tab, active ? band : NWL - 1);
@@ -230,8 +245,10 @@ template <typename T>
 __global__ __launch_bounds__(TILE) void k_bsm(const T* __restrict__ tab, const T* __restrict__ cst, int64_t B,
                                               int chunk, const T* __restrict__ rdry_in, T* __restrict__ o_refl,
                                               T* __restrict__ o_dry) {
-  const int tile = blockIdx.x % NTILE;
-  const int64_t ck = blockIdx.x / NTILE;
+  int tile;
+  int64_t ck;
+  xcd_map(blockIdx.x, tile, ck);
+  if (ck * chunk >= B) return;
   const int band = tile * TILE + threadIdx.x;
   const bool active = band < NWL;
   const BandTab<T> tb = load_tab(tab, active ? band : NWL - 1);

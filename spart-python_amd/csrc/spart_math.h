@@ -392,7 +392,8 @@ SPART_HD void canopy_band(const CanopyPar<T>& c, T rho, T tau, T absb, T rs, T& 
 // sample-level (band independent) arithmetic: always double
 // ------------------------------------------------------------------------------------------
 
-// calculate_leafangles.dcum (sailh.py:368-384)
+// calculate_leafangles.dcum (sailh.py:368-384), literal fixed-point iteration with the reference's
+// stopping rule; y = a sin x + b/2 sin 2x is evaluated as sin x (a + b cos x) (one sincos per step).
 SPART_HD double lidf_dcum(double a, double b, double theta_deg) {
   const double rd = PI / 180.0;
   if (a > 1.0) return 1.0 - ::cos(theta_deg * rd);  // :371-372
@@ -401,11 +402,34 @@ SPART_HD double lidf_dcum(double a, double b, double theta_deg) {
   double y = 0.0, dx;
   int it = 0;
   do {  // :378-382; the cap only guards against non-convergence for non-physical |a|+|b| >> 1
-    y = a * ::sin(x) + 0.5 * b * ::sin(2.0 * x);
+    double sn, cs;
+    ::sincos(x, &sn, &cs);
+    y = sn * (a + b * cs);
     dx = 0.5 * (y - x + theta2);
     x += dx;
   } while (::fabs(dx) > 1e-8 && ++it < 100000);
   return (2.0 * y + theta2) / PI;
+}
+
+// The same cumulative distribution from the exact root of x = theta2 + a sin x + b/2 sin 2x (Newton,
+// quadratic convergence).  The reference stops its linear iteration at |dx| <= 1e-8, i.e. its F carries
+// an error of up to ~5e-8; the root differs from it by that much.  Used by the float32 path only
+// (tolerance 1e-4); |a| + |b| >= 0.95 (derivative may vanish) falls back to the literal iteration.
+SPART_HD double lidf_dcum_newton(double a, double b, double theta_deg) {
+  if (!(::fabs(a) + ::fabs(b) < 0.95)) return lidf_dcum(a, b, theta_deg);
+  const double rd = PI / 180.0;
+  const double theta2 = 2.0 * rd * theta_deg;
+  double x = theta2;
+  for (int it = 0; it < 12; ++it) {
+    double sn, cs;
+    ::sincos(x, &sn, &cs);
+    double f = x - theta2 - sn * (a + b * cs);
+    double fp = 1.0 - a * cs - b * (2.0 * cs * cs - 1.0);
+    double d = f / fp;
+    x -= d;
+    if (::fabs(d) < 1e-13) break;
+  }
+  return (2.0 * (x - theta2) + theta2) / PI;
 }
 
 // F(theta_i) nodes: 10..80 step 10, 82..88 step 2, then F = 1   (sailh.py:388-394)
@@ -471,12 +495,23 @@ struct PsoFn {
   }
 };
 
-SPART_HD double gl16_panel(const PsoFn& f, double a, double b) {
+// 8-point rule (float32 path: panels are halved until rate * h <= 2, error ~1e-9 per panel)
+static constexpr double GL8_X[4] = {0.1834346424956498049394761, 0.5255324099163289858177390,
+                                    0.7966664774136267395915539, 0.9602898564975362316835609};
+static constexpr double GL8_W[4] = {0.3626837833783619829651504, 0.3137066458778872873379622,
+                                    0.2223810344533744705443560, 0.1012285362903762591525314};
+
+template <bool FAST> SPART_HD double gl_panel(const PsoFn& f, double a, double b) {
   double h = 0.5 * (b - a), c = 0.5 * (b + a), s = 0.0;
-  for (int i = 0; i < 8; ++i) s += GL16_W[i] * (f(c + h * GL16_X[i]) + f(c - h * GL16_X[i]));
+  if (FAST) {
+    for (int i = 0; i < 4; ++i) s += GL8_W[i] * (f(c + h * GL8_X[i]) + f(c - h * GL8_X[i]));
+  } else {
+    for (int i = 0; i < 8; ++i) s += GL16_W[i] * (f(c + h * GL16_X[i]) + f(c - h * GL16_X[i]));
+  }
   return s * h;
 }
 
+template <bool FAST>
 SPART_HD void hotspot_integrals(double K, double k, double LAI, double q, double dso, double& int_canopy,
                                 double& pso2w) {
   const double dx = 1.0 / NLAYER;
@@ -495,28 +530,32 @@ SPART_HD void hotspot_integrals(double K, double k, double LAI, double q, double
     f.A = (K + k) * LAI - ::sqrt(K * k) * LAI;
     rate = f.A;
   }
-  // number of halvings so that rate * 2^-m <= 4 (NaN / inf rates fall through with m = 0 / 40)
+  // number of halvings so that rate * 2^-m <= 4 (2 for the 8-point rule); NaN / inf rates fall through
+  // with m = 0 / 40
+  const double lim = FAST ? 2.0 : 4.0;
   int m = 0;
   double hw = 1.0;
-  while (rate * hw > 4.0 && m < 40) {
+  while (rate * hw > lim && m < 40) {
     hw *= 0.5;
     ++m;
   }
   double tot = 0.0, lo = -1.0;
   for (int i = 0; i < m; ++i) {
-    tot += gl16_panel(f, lo, 0.5 * lo);
+    tot += gl_panel<FAST>(f, lo, 0.5 * lo);
     lo *= 0.5;
   }
-  tot += gl16_panel(f, lo, 0.0);
+  tot += gl_panel<FAST>(f, lo, 0.0);
   int_canopy = tot;
-  pso2w = gl16_panel(f, -1.0 - dx, -1.0) / dx;
+  pso2w = gl_panel<false>(f, -1.0 - dx, -1.0) / dx;
 }
 
 // ------------------------------------------------------------------------------------------
 // The prelude: 27 parameters -> band-kernel constants (T) + atmosphere scalars (double)
 enum PreludeMask { PRE_LEAF = 1, PRE_SOIL = 2, PRE_CANOPY = 4, PRE_ATM = 8, PRE_ALL = 15 };
 
-template <typename T>
+// FAST (used for T = float, tolerance 1e-4): Newton LIDF and the 8-point hot-spot rule, both ~1e-7 from
+// the literal forms; T = double keeps the reference's iteration and the 16-point rule.
+template <typename T, bool FAST = false>
 SPART_HD void sample_prelude(const double* p /*[27]*/, double rho_th, double tau_th, int mask, T* cst /*[NCONST]*/,
                              double* atm /*[NATM]*/, double* lidf_out /*[13]*/) {
   SPART_NO_CONTRACT
@@ -576,7 +615,9 @@ SPART_HD void sample_prelude(const double* p /*[27]*/, double rho_th, double tau
   double dso = ::sqrt(tan_tts * tan_tts + tan_tto * tan_tto - 2.0 * tan_tts * tan_tto * ::cos(psi_rad));  // :78
   double ks = 0, ko = 0, bf = 0, sob = 0, sof = 0, Fprev = 0;
   for (int i = 0; i < NLINCL; ++i) {
-    double F = (i < NLINCL - 1) ? lidf_dcum(LIDFa, LIDFb, lidf_theta(i)) : 1.0;
+    double F = (i < NLINCL - 1) ? (FAST ? lidf_dcum_newton(LIDFa, LIDFb, lidf_theta(i))
+                                        : lidf_dcum(LIDFa, LIDFb, lidf_theta(i)))
+                                : 1.0;
     double li = F - Fprev;
     Fprev = F;
     lidf_out[i] = li;
@@ -607,7 +648,7 @@ SPART_HD void sample_prelude(const double* p /*[27]*/, double rho_th, double tau
   cst[C_TOO] = T(too);
   cst[C_Z] = T((1.0 - tss * too) / (ko + ks));             // :203
   double ic, p2w;
-  hotspot_integrals(ko, ks, LAI, q, dso, ic, p2w);
+  hotspot_integrals<FAST>(ko, ks, LAI, q, dso, ic, p2w);
   cst[C_HOT] = T(ic * LAI);   // sum(Pso[0:60]) * iLAI  (:216)
   cst[C_PSO2W] = T(p2w);      // Pso[60]               (:219)
   }

@@ -25,7 +25,7 @@ static void bands_impl(int64_t B, const double* tab, const double* P, double* ou
   for (int64_t s = 0; s < B; ++s) {
     T c[NCONST];
     double a[NATM], li[NLINCL];
-    sample_prelude<T>(P + s * NPARAM, 0.01, 0.01, PRE_ALL, c, a, li);
+    sample_prelude<T, (sizeof(T) == 4)>(P + s * NPARAM, 0.01, 0.01, PRE_ALL, c, a, li);
     std::memcpy(atm_out + s * NATM, a, sizeof(a));
     std::memcpy(lidf_out + s * NLINCL, li, sizeof(li));
     CanopyPar<T> cp;

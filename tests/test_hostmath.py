@@ -94,7 +94,7 @@ def test_chain_vs_oracle_and_reference(hm, tab, oracle, tables, golden, dtype, t
             assert rel_err(out[:, :, 5 + q], ref[k][:, :2002], fl) < tol_spec, k
         # carried absorptance == 1 - refl - tran
         assert rel_err(out[:, :2001, 9], 1 - ref["leaf_refl"] - ref["leaf_tran"], 1e-2) < (1e-9 if dtype == 1 else 3e-6)
-        assert np.max(np.abs(lidf - ref["aux"]["lidf"])) < 1e-14
+        assert np.max(np.abs(lidf - ref["aux"]["lidf"])) < (1e-14 if dtype == 1 else 2e-7)   # fp32 path: Newton root vs the 1e-8 stopping rule
         for q, k in enumerate(oracle.SMAC_OUT):
             assert rel_err(sm[:, :, q], ref["atm_" + k], 1e-6) < 1e-10, k
         # sensor columns against the REAL reference's outputs
