@@ -350,8 +350,12 @@ SPART_HD void canopy_band(const CanopyPar<T>& c, T rho, T tau, T absb, T rs, T& 
   T a = T(1) - sigf;                   // :149
   // m^2 = a^2 - sigb^2 = (a - sigb)(a + sigb), a - sigb = 1 - rho - tau   (:150)
   T m = Mx<T>::sqrt(absb * (a + sigb));
-  T rinf = sigb * Mx<T>::rcp(a + m);   // == (a - m)/sigb   (:151)
+  T iam = Mx<T>::rcp(a + m);
+  T rinf = sigb * iam;                 // == (a - m)/sigb   (:151)
   T rinf2 = rinf * rinf;
+  // 1 - rinf = (a - sigb + m)/(a + m) = (absorptance + m)/(a + m): no cancellation for nearly
+  // conservative leaves (rinf -> 1)
+  T omr2 = (absb + m) * iam * (T(1) + rinf);   // 1 - rinf^2
   T L = c.lai;
   // J1(-1) = (e^-mL - e^-kL)/(k - m) = L e^-kL phi((m-k)L)   (:154-170, 180-183)
   T e1 = Mx<T>::exp(-m * L);           // :185-189
@@ -361,17 +365,17 @@ SPART_HD void canopy_band(const CanopyPar<T>& c, T rho, T tau, T absb, T rs, T& 
   T iks = Mx<T>::rcp(c.ks + m), iko = Mx<T>::rcp(c.ko + m);
   T J2k = SailJ<T>::j2(L, c.tss, e1, c.ks + m, iks);
   T J2K = SailJ<T>::j2(L, c.too, e1, c.ko + m, iko);
-  T e2 = e1 * e1;
+  T ome2 = T(1) - e1 * e1;
   T re = rinf * e1;
-  T i1 = Mx<T>::rcp(T(1) - rinf2 * rinf2);  // sic: 1 - rinf2**2 (:189)
-  T i2 = (T(1) + rinf2) * i1;                // 1/(1 - rinf2)  (:214)
+  T i1 = Mx<T>::rcp(omr2 * (T(1) + rinf2));  // sic: 1/(1 - rinf2**2) (:189)
+  T i2 = (T(1) + rinf2) * i1;                 // 1/(1 - rinf2)  (:214)
   T s1 = sf + rinf * sb;               // :191-198
   T s2 = sf * rinf + sb;
   T v1 = vf + rinf * vb;
   T v2 = vf * rinf + vb;
   T Pss = s1 * J1k, Qss = s2 * J2k, Poo = v1 * J1K, Qoo = v2 * J2K;
-  T tau_dd = (T(1) - rinf2) * e1 * i1;  // :205-210
-  T rho_dd = rinf * (T(1) - e2) * i1;
+  T tau_dd = omr2 * e1 * i1;             // :205-210
+  T rho_dd = rinf * ome2 * i1;
   T tau_sd = (Pss - re * Qss) * i1;
   T tau_do = (Poo - re * Qoo) * i1;
   T rho_sd = (Qss - re * Pss) * i1;

@@ -143,25 +143,25 @@ def test_ragged_and_edge_batches(oracle, tables, torch_mod):
 
 
 def test_full_size_properties(torch_mod):
-    """BASELINE size (1M spectra, fp32): size-independent checks -- finite, positive-band sanity
-    against a 4096-row fp64 re-evaluation of scattered rows, and batch-split invariance."""
+    """BASELINE size (1M spectra, config-4 workload): size-independent checks.
+    (1) every fp32 column entry against the fp64 evaluation of the SAME 1M rows (fp64 itself is pinned to
+        the oracle / reference by the tests above): max |d| / max(|ref|, 1e-3) < 1e-4 over all 13M entries;
+    (2) evaluating the batch in two ragged halves gives bit-identical columns (samples are independent);
+    (3) batch-mean spectra (all 2162 bands of all samples) agree between fp32 and fp64."""
     from spart_amd import get_engine, workloads
     eng = get_engine("Sentinel2A-MSI", 0)
     B = 1_000_000
     P = torch_mod.as_tensor(workloads.lhs_params(B, "full").T.copy(), device="cuda:0")
-    out = eng.run(P, "float32")
+    o64 = {k: v.clone() for k, v in eng.run(P, "float64", materialize=("band_mean",)).items()}
+    out = {k: v.clone() for k, v in eng.run(P, "float32", materialize=("band_mean",)).items()}
     for k in ("R_TOC", "R_TOA", "L_TOA"):
         assert torch_mod.isfinite(out[k]).all()
-    idx = torch_mod.arange(0, B, B // 4096, device="cuda:0")[:4096]
-    sub = eng.run(P[:, idx].contiguous(), "float64")
-    for k in ("R_TOC", "R_TOA", "L_TOA"):
-        a, b = out[k][idx].double(), sub[k]
-        err = ((a - b).abs() / b.abs().clamp_min(1e-3)).max().item()
+        err = ((out[k].double() - o64[k]).abs() / o64[k].abs().clamp_min(1e-3)).max().item()
         assert err < 1e-4, (k, err)
-    # evaluating the batch in two halves gives bit-identical columns (samples are independent)
+    bm_err = ((out["band_mean"].double() - o64["band_mean"]).abs() / o64["band_mean"].abs().clamp_min(1e-3)).max().item()
+    assert bm_err < 1e-4, bm_err
     h = B // 2 + 13
-    o1 = eng.run(P[:, :h].contiguous(), "float32")
-    o1 = {k: v.clone() for k, v in o1.items()}
+    o1 = {k: v.clone() for k, v in eng.run(P[:, :h].contiguous(), "float32").items()}
     o2 = eng.run(P[:, h:].contiguous(), "float32")
     for k in ("R_TOC", "R_TOA", "L_TOA"):
         assert torch_mod.equal(torch_mod.cat([o1[k], o2[k]]), out[k])
