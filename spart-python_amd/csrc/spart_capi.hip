@@ -238,10 +238,16 @@ static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_
     HIP_TRY(ctx, hipGetLastError());
   }
   SensorTab stb{ctx->slot0, ctx->slot1, ctx->frac, ctx->coef, ctx->econv, ctx->nb, ctx->nslot};
-  int64_t n = B * ctx->nb;
-  hipLaunchKernelGGL((k_sensor<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, stb, (const T*)G,
-                     (const double*)atm, B, (T*)R_TOC, (T*)R_TOA, (T*)L_TOA, (const T*)(opt && opt->rsoil ? gs : nullptr),
-                     (T*)(opt ? opt->rsoil : nullptr), (T*)(opt ? opt->La : nullptr));
+  {
+    const bool want_rsoil = opt && opt->rsoil;
+    const int narr = 3 + (want_rsoil ? 1 : 0) + ((opt && opt->La) ? 1 : 0);
+    const size_t lds = (size_t)narr * 64 * ctx->nb * sizeof(T);      // <= 5 * 64 * 64 * 8 = 160 KiB only for nb = 64 fp64
+    if (lds > 64 * 1024) return fail(ctx, SPART_ERR_INVALID, "spart_run_batch: %d sensor bands need %zu B of LDS staging", ctx->nb, lds);
+    const int nwave = ctx->nb < 16 ? ctx->nb : 16;
+    hipLaunchKernelGGL((k_sensor<T>), dim3((unsigned)((B + 63) / 64)), dim3(64 * nwave), lds, st, stb, (const T*)G,
+                       (const double*)atm, B, (T*)R_TOC, (T*)R_TOA, (T*)L_TOA, (const T*)(want_rsoil ? gs : nullptr),
+                       (T*)(opt ? opt->rsoil : nullptr), (T*)(opt ? opt->La : nullptr));
+  }
   HIP_TRY(ctx, hipGetLastError());
   return SPART_OK;
 }

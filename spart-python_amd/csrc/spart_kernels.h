@@ -305,37 +305,71 @@ struct SensorTab {
   int nb, nslot;
 };
 
+// Mapping: a workgroup owns 64 consecutive samples (lane = sample); wave w walks the sensor bands
+// j = w, w + nwave, ... so that the band index -- and with it the 48 SMAC coefficients, the interpolation
+// slots and the "is this gas absent in this band" tests -- is wave-uniform (scalar loads, scalar branches).
+// Results are staged in LDS and written out as whole (64 x nb) row blocks, coalesced.
 template <typename T>
-__global__ __launch_bounds__(256) void k_sensor(SensorTab st, const T* __restrict__ G, const double* __restrict__ atm,
-                                                int64_t B, T* __restrict__ R_TOC, T* __restrict__ R_TOA,
-                                                T* __restrict__ L_TOA, const T* __restrict__ gsoil,
-                                                T* __restrict__ o_rsoil, T* __restrict__ o_La) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B * st.nb) return;
-  int64_t s = i / st.nb;
-  int j = (int)(i - s * st.nb);
-  const T* g0 = G + (s * st.nslot + st.slot0[j]) * 4;
-  const T* g1 = G + (s * st.nslot + st.slot1[j]) * 4;
-  double f = st.frac[j];
-  double v[4];
+__global__ __launch_bounds__(1024) void k_sensor(SensorTab st, const T* __restrict__ G, const double* __restrict__ atm,
+                                                 int64_t B, T* __restrict__ R_TOC, T* __restrict__ R_TOA,
+                                                 T* __restrict__ L_TOA, const T* __restrict__ gsoil,
+                                                 T* __restrict__ o_rsoil, T* __restrict__ o_La) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* stage = reinterpret_cast<T*>(smem_raw);          // [narr][64 * nb]
+  const int nb = st.nb;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int nwave = (int)(blockDim.x >> 6);
+  const int64_t s0 = (int64_t)blockIdx.x * 64;
+  const int64_t s = s0 + lane;
+  const bool ok = s < B;
+  const int64_t sc = ok ? s : B - 1;
+  double a[NATM];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    double y0 = (double)g0[q], y1 = (double)g1[q];
-    v[q] = y0 + (y1 - y0) * f;
+  for (int i = 0; i < NATM; ++i) a[i] = atm[sc * NATM + i];
+  const int tile = 64 * nb;
+  for (int j = wave; j < nb; j += nwave) {
+    const int sl0 = st.slot0[j], sl1 = st.slot1[j];
+    const double f = st.frac[j];
+    const T* g0 = G + (sc * st.nslot + sl0) * 4;
+    const T* g1 = G + (sc * st.nslot + sl1) * 4;
+    double v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      double y0 = (double)g0[q], y1 = (double)g1[q];
+      v[q] = y0 + (y1 - y0) * f;                     // np.interp (SPART.py:220-223)
+    }
+    SmacOut so = smac_band(a, st.coef + j, nb);
+    double La = a[A_LAF] * st.econv[j];              // SPART.py:353, 394
+    double rtoc, rtoa, ltoa;
+    toc_to_toa(so, v[0], v[1], v[3], v[2], La, rtoc, rtoa, ltoa);  // G order: rso, rdo, rsd, rdd
+    const int o = lane * nb + j;
+    stage[o] = (T)rtoc;
+    stage[tile + o] = (T)rtoa;
+    stage[2 * tile + o] = (T)ltoa;
+    int na = 3;
+    if (o_rsoil && gsoil) {
+      double y0 = (double)gsoil[sc * st.nslot + sl0], y1 = (double)gsoil[sc * st.nslot + sl1];
+      stage[na * tile + o] = (T)(y0 + (y1 - y0) * f);
+      ++na;
+    }
+    if (o_La) stage[na * tile + o] = (T)La;
   }
-  const double* a = atm + s * NATM;
-  SmacOut so = smac_band(a, st.coef + j, st.nb);
-  double La = a[A_LAF] * st.econv[j];     // SPART.py:353, 394
-  double rtoc, rtoa, ltoa;
-  toc_to_toa(so, v[0], v[1], v[3], v[2], La, rtoc, rtoa, ltoa);  // G order: rso, rdo, rsd, rdd
-  R_TOC[i] = (T)rtoc;
-  R_TOA[i] = (T)rtoa;
-  L_TOA[i] = (T)ltoa;
-  if (o_rsoil && gsoil) {
-    double y0 = (double)gsoil[s * st.nslot + st.slot0[j]], y1 = (double)gsoil[s * st.nslot + st.slot1[j]];
-    o_rsoil[i] = (T)(y0 + (y1 - y0) * f);
+  __syncthreads();
+  const int64_t rem = B - s0;
+  const int n = (int)((rem < 64 ? rem : 64) * nb);
+  const int64_t base = s0 * nb;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    R_TOC[base + i] = stage[i];
+    R_TOA[base + i] = stage[tile + i];
+    L_TOA[base + i] = stage[2 * tile + i];
+    int na = 3;
+    if (o_rsoil && gsoil) {
+      o_rsoil[base + i] = stage[na * tile + i];
+      ++na;
+    }
+    if (o_La) o_La[base + i] = stage[na * tile + i];
   }
-  if (o_La) o_La[i] = (T)La;
 }
 
 // standalone SMAC: nine (B,nb) float64 outputs

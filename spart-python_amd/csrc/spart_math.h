@@ -340,16 +340,19 @@ template <typename T> struct CanopyPar {
 
 template <typename T>
 SPART_HD void canopy_band(const CanopyPar<T>& c, T rho, T tau, T absb, T rs, T& rso, T& rdo, T& rsd, T& rdd) {
-  T sigb = c.ddb * rho + c.ddf * tau;  // :142-148
-  T sigf = c.ddf * rho + c.ddb * tau;
-  T sb = c.sdb * rho + c.sdf * tau;
-  T sf = c.sdf * rho + c.sdb * tau;
-  T vb = c.dob * rho + c.dof * tau;
-  T vf = c.dof * rho + c.dob * tau;
-  T w = c.sob * rho + c.sof * tau;
+  // scattering coefficients (:142-148).  With sdb/sdf = (k +- bf)/2, ddb/ddf = (1 +- bf)/2, dob/dof = (K +- bf)/2
+  // (:100-105) they are P, k P, K P plus/minus Mn, where P = (rho + tau)/2 and Mn = bf (rho - tau)/2:
+  T P = T(0.5) * (rho + tau);
+  T Mn = (T(0.5) * c.bf) * (rho - tau);
+  T sigb = P + Mn;                     // diffuse backscatter
+  T sigf = P - Mn;                     // diffuse forward scatter
+  T kP = c.ks * P, KP = c.ko * P;
+  T sb = kP + Mn, sf = kP - Mn;        // specular back / forward
+  T vb = KP + Mn, vf = KP - Mn;        // directional back / forward
+  T w = c.sob * rho + c.sof * tau;     // bidirectional
   T a = T(1) - sigf;                   // :149
-  // m^2 = a^2 - sigb^2 = (a - sigb)(a + sigb), a - sigb = 1 - rho - tau   (:150)
-  T m = Mx<T>::sqrt(absb * (a + sigb));
+  // m^2 = a^2 - sigb^2 = (a - sigb)(a + sigb), a - sigb = 1 - rho - tau, a + sigb = 1 + 2 Mn   (:150)
+  T m = Mx<T>::sqrt(absb * (T(1) + T(2) * Mn));
   T iam = Mx<T>::rcp(a + m);
   T rinf = sigb * iam;                 // == (a - m)/sigb   (:151)
   T rinf2 = rinf * rinf;
@@ -700,18 +703,24 @@ SPART_HD SmacOut smac_band(const double* atm, const double* coef, int cs) {
   double us = atm[A_US], uv = atm[A_UV], m = atm[A_M], Peq = atm[A_PEQ], Pa = atm[A_PA];
   double taup550 = atm[A_AOT], uo3 = atm[A_UO3], uh2o = atm[A_UH2O], cksi = atm[A_CKSI], ksiD = atm[A_KSID];
   double taup = C(K_A0TAUP) + C(K_A1TAUP) * taup550;  // :103
-  double uo2 = ::pow(Peq, C(K_PO2));                   // :105-109
-  double uco2 = ::pow(Peq, C(K_PCO2));
-  double uch4 = ::pow(Peq, C(K_PCH4));
-  double uno2 = ::pow(Peq, C(K_PNO2));
-  double uco = ::pow(Peq, C(K_PCO));
-  double to3 = ::exp(C(K_AO3) * ::pow(uo3 * m, C(K_NO3)));  // :111-117
-  double th2o = ::exp(C(K_AH2O) * ::pow(uh2o * m, C(K_NH2O)));
-  double to2 = ::exp(C(K_AO2) * ::pow(uo2 * m, C(K_NO2)));
-  double tco2 = ::exp(C(K_ACO2) * ::pow(uco2 * m, C(K_NCO2)));
-  double tch4 = ::exp(C(K_ACH4) * ::pow(uch4 * m, C(K_NCH4)));
-  double tno2 = ::exp(C(K_ANO2) * ::pow(uno2 * m, C(K_NNO2)));
-  double tco = ::exp(C(K_ACO) * ::pow(uco * m, C(K_NCO)));
+  // gaseous transmittances t = exp(a (u m)^n), u = Peq^p (:105-119).  A gas whose coefficient a is zero in
+  // this band has t = exp(0) = 1 exactly (most of CO, CH4, NO2, O2, CO2 in most bands): its two pow/exp
+  // calls are skipped, which leaves the product below bit-identical.
+  auto gas = [&](int ka, int kn, double um) -> double {
+    double av = C(ka);
+    return (av != 0.0) ? ::exp(av * ::pow(um, C(kn))) : 1.0;
+  };
+  auto pgas = [&](int ka, int kn, int kp) -> double {
+    double av = C(ka);
+    return (av != 0.0) ? ::exp(av * ::pow(::pow(Peq, C(kp)) * m, C(kn))) : 1.0;
+  };
+  double to3 = gas(K_AO3, K_NO3, uo3 * m);
+  double th2o = gas(K_AH2O, K_NH2O, uh2o * m);
+  double to2 = pgas(K_AO2, K_NO2, K_PO2);
+  double tco2 = pgas(K_ACO2, K_NCO2, K_PCO2);
+  double tch4 = pgas(K_ACH4, K_NCH4, K_PCH4);
+  double tno2 = pgas(K_ANO2, K_NNO2, K_PNO2);
+  double tco = pgas(K_ACO, K_NCO, K_PCO);
   SmacOut o;
   o.Tg = th2o * to3 * to2 * tco2 * tch4 * tco * tno2;  // :119
   o.Ra_dd = C(K_A0S) * Peq + C(K_A3S) + C(K_A1S) * taup550 + C(K_A2S) * taup550 * taup550;  // :122
