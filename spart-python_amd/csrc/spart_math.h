@@ -177,10 +177,10 @@ template <> struct E3c<double> {
 
 template <typename T> SPART_HD void plate_tau(T K, T& tau, T& u) {
   using C = E3c<T>;
-  // K <= 0 (and NaN, as in the reference where only Kall > 0 entries are replaced, prospect_5d.py:182,195)
-  // is clamped to a tiny positive value: tau -> 1, u -> 0+, and the Stokes terms below reach the
-  // reference's zero-absorption limit (prospect_5d.py:233-235) continuously.
-  T x = Mx<T>::fmax(K, Mx<T>::tiny());
+  // K <= 0 (only Kall > 0 entries are replaced in the reference, prospect_5d.py:182,195) is clamped to a
+  // tiny positive value: tau -> 1, u -> 0+, and the Stokes terms below reach the reference's
+  // zero-absorption limit (prospect_5d.py:233-235) continuously.  NaN propagates.
+  T x = (K < Mx<T>::tiny()) ? Mx<T>::tiny() : K;   // (a select, not fmax: a NaN K must stay NaN)
   const bool small = x < T(1);
   T v;  // u on the small branch, tau on the large one (one value, so nothing is spilled to select them)
   if (small) {
