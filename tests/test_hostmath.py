@@ -19,7 +19,7 @@ def hm():
     src = os.path.join(HM, "hostmath.cpp")
     hdr = os.path.join(ROOT, "spart-python_amd", "csrc", "spart_math.h")
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", "-w", "-o", so, src])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", "-w", "-DSPART_FAST_MATH=1", "-o", so, src])
     return ctypes.CDLL(so)
 
 
