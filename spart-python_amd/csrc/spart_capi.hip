@@ -252,6 +252,43 @@ static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_
   return SPART_OK;
 }
 
+// LUT inversion: number of row slices so that (M/256) x nslice workgroups fill 256 CUs several times over
+static int lut_slices(int64_t M) {
+  int64_t mb = (M + 255) / 256;
+  int64_t n = (4096 + mb - 1) / mb;
+  if (n < 1) n = 1;
+  if (n > 1024) n = 1024;
+  return (int)n;
+}
+
+static int lut_nbp(int nb) { return nb <= 15 ? 16 : 32; }
+
+template <typename T>
+static int lut_impl(spart_ctx* ctx, int64_t B, int nb, const void* lut, int64_t M, const void* obs, const void* weights,
+                    int64_t* best_idx, void* best_cost, char* wsp, hipStream_t st) {
+  const int nslice = lut_slices(M);
+  const int nbp = lut_nbp(nb);
+  T* padded = (T*)wsp;
+  T* pc = (T*)(wsp + align_up((size_t)B * nbp * sizeof(T)));
+  int64_t* pi = (int64_t*)((char*)pc + align_up((size_t)nslice * M * sizeof(T)));
+  dim3 gprep((unsigned)((B + 255) / 256));
+  dim3 grid((unsigned)((M + 255) / 256), (unsigned)nslice);
+  if (nbp == 16) {
+    hipLaunchKernelGGL((k_lut_prep<T, 16>), gprep, dim3(256), 0, st, (const T*)lut, (const T*)weights, nb, B, padded);
+    hipLaunchKernelGGL((k_lut_scan<T, 16>), grid, dim3(256), 0, st, (const T*)padded, (const T*)obs, (const T*)weights, nb,
+                       B, M, nslice, pc, pi);
+  } else {
+    hipLaunchKernelGGL((k_lut_prep<T, 32>), gprep, dim3(256), 0, st, (const T*)lut, (const T*)weights, nb, B, padded);
+    hipLaunchKernelGGL((k_lut_scan<T, 32>), grid, dim3(256), 0, st, (const T*)padded, (const T*)obs, (const T*)weights, nb,
+                       B, M, nslice, pc, pi);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  hipLaunchKernelGGL((k_lut_reduce<T>), dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, (const T*)pc, (const int64_t*)pi,
+                     (const T*)obs, (const T*)weights, nb, M, nslice, best_idx, (T*)best_cost);
+  HIP_TRY(ctx, hipGetLastError());
+  return SPART_OK;
+}
+
 extern "C" {
 
 const char* spart_last_error(const spart_ctx* ctx) { return ctx ? ctx->err : g_err; }
@@ -514,6 +551,31 @@ int spart_run_batch(spart_ctx* ctx, int dtype, int64_t B, const double* const pa
   return dtype == SPART_F32
              ? run_impl<float>(ctx, B, params, rho_thermal, tau_thermal, R_TOC, R_TOA, L_TOA, opt, wsp, ws, st)
              : run_impl<double>(ctx, B, params, rho_thermal, tau_thermal, R_TOC, R_TOA, L_TOA, opt, wsp, ws, st);
+}
+
+size_t spart_lut_workspace_bytes(int dtype, int64_t B, int nb, int64_t M) {
+  if (B <= 0 || M <= 0 || nb < 1) return 0;
+  size_t es = dtype == SPART_F64 ? 8 : 4;
+  int nslice = lut_slices(M);
+  return align_up((size_t)B * lut_nbp(nb) * es) + align_up((size_t)nslice * M * es) + align_up((size_t)nslice * M * 8);
+}
+
+int spart_lut_nearest(spart_ctx* ctx, int dtype, int64_t B, int nb, const void* lut, int64_t M, const void* obs,
+                      const void* weights, int64_t* best_idx, void* best_cost, void* workspace, size_t workspace_bytes,
+                      void* stream) {
+  if (!ctx) return fail(nullptr, SPART_ERR_INVALID, "spart_lut_nearest: null context");
+  if (dtype != SPART_F32 && dtype != SPART_F64) return fail(ctx, SPART_ERR_INVALID, "spart_lut_nearest: bad dtype %d", dtype);
+  if (B < 0 || M < 0 || nb < 1 || nb > 31) return fail(ctx, SPART_ERR_INVALID, "spart_lut_nearest: bad sizes (B=%lld M=%lld nb=%d, nb <= 31)", (long long)B, (long long)M, nb);
+  if (M == 0) return SPART_OK;
+  if (B == 0) return fail(ctx, SPART_ERR_INVALID, "spart_lut_nearest: empty LUT");
+  if (!lut || !obs || !best_idx || !best_cost) return fail(ctx, SPART_ERR_INVALID, "spart_lut_nearest: null argument");
+  size_t need = spart_lut_workspace_bytes(dtype, B, nb, M);
+  if (!workspace || workspace_bytes < need)
+    return fail(ctx, SPART_ERR_WORKSPACE, "spart_lut_nearest: workspace of %zu bytes needed, %zu given", need, workspace_bytes);
+  DeviceGuard guard(ctx->device);
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == SPART_F32 ? lut_impl<float>(ctx, B, nb, lut, M, obs, weights, best_idx, best_cost, (char*)workspace, st)
+                            : lut_impl<double>(ctx, B, nb, lut, M, obs, weights, best_idx, best_cost, (char*)workspace, st);
 }
 
 }  // extern "C"

@@ -418,4 +418,86 @@ __global__ __launch_bounds__(64) void k_econv(const double* __restrict__ Ea, con
   if (lane == 0) econv[b] = num / den;
 }
 
+// ------------------------------------------------------------------------------------------
+// LUT inversion (no counterpart in the reference): for every observed spectrum find the LUT
+// row with the smallest weighted squared distance  sum_j w_j (x_bj - y_mj)^2.
+//   cost(b, m) = n_b + sum_j x_bj * (-2 w_j y_mj) + sum_j w_j y_mj^2,   n_b = sum_j w_j x_bj^2 (k_lut_norms)
+// Mapping: lane = observation (its -2 w y in VGPRs for the whole scan), LUT rows are wave-uniform and stream
+// through scalar loads; the LUT is cut into `nslice` row ranges so that M/256 x nslice workgroups fill the chip;
+// k_lut_reduce takes the minimum over slices.  NaN rows never win (comparisons with NaN are false).
+// pre-pass: rows re-laid out as NBP (16 or 32) values, NBP*sizeof(T)-aligned, so that one s_load_dwordx16
+// (x32) fetches a whole row: [x_0 .. x_{nb-1}, 0 .., n_b] with the weighted norm n_b in the last slot
+template <typename T, int NBP>
+__global__ __launch_bounds__(256) void k_lut_prep(const T* __restrict__ lut, const T* __restrict__ w, int nb, int64_t B,
+                                                  T* __restrict__ padded) {
+  int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  T acc = T(0);
+  T* dst = padded + b * NBP;
+  for (int j = 0; j < NBP - 1; ++j) {
+    T x = j < nb ? lut[b * nb + j] : T(0);
+    acc += (w && j < nb ? w[j] : T(1)) * x * x;
+    dst[j] = x;
+  }
+  dst[NBP - 1] = acc;
+}
+
+template <typename T, int NBP>
+__global__ __launch_bounds__(256) void k_lut_scan(const T* __restrict__ padded, const T* __restrict__ obs,
+                                                  const T* __restrict__ w, int nb, int64_t B, int64_t M, int nslice,
+                                                  T* __restrict__ part_cost, int64_t* __restrict__ part_idx) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int slice = blockIdx.y;
+  const int64_t mc = m < M ? m : M - 1;
+  T yw[NBP - 1];
+#pragma unroll
+  for (int j = 0; j < NBP - 1; ++j) yw[j] = (j < nb) ? T(-2) * (w ? w[j] : T(1)) * obs[mc * nb + j] : T(0);
+  const int64_t per = (B + nslice - 1) / nslice;
+  const int64_t b0 = per * slice;
+  const int64_t b1 = (b0 + per < B) ? b0 + per : B;
+  T best = INFINITY;
+  int64_t bi = -1;
+#pragma unroll 2
+  for (int64_t b = b0; b < b1; ++b) {
+    const T* __restrict__ x = padded + b * NBP;   // wave-uniform, NBP-aligned row -> one wide scalar load
+    T acc = x[NBP - 1];
+#pragma unroll
+    for (int j = 0; j < NBP - 1; ++j) acc += x[j] * yw[j];
+    if (acc < best) {
+      best = acc;
+      bi = b;
+    }
+  }
+  if (m < M) {
+    part_cost[(int64_t)slice * M + m] = best;
+    part_idx[(int64_t)slice * M + m] = bi;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_lut_reduce(const T* __restrict__ part_cost, const int64_t* __restrict__ part_idx,
+                                                    const T* __restrict__ obs, const T* __restrict__ w, int nb, int64_t M,
+                                                    int nslice, int64_t* __restrict__ best_idx,
+                                                    T* __restrict__ best_cost) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  T best = INFINITY;
+  int64_t bi = -1;
+  for (int s = 0; s < nslice; ++s) {             // ascending slices + strict '<': ties go to the lowest row index
+    T c = part_cost[(int64_t)s * M + m];
+    if (c < best) {
+      best = c;
+      bi = part_idx[(int64_t)s * M + m];
+    }
+  }
+  T yy = T(0);
+  for (int j = 0; j < nb; ++j) {
+    T y = obs[m * nb + j];
+    yy += (w ? w[j] : T(1)) * y * y;
+  }
+  best_idx[m] = bi;
+  T c = best + yy;
+  best_cost[m] = c > T(0) ? c : T(0);             // weighted sum of squared differences (rounding can leave -1e-9)
+}
+
 }  // namespace spart

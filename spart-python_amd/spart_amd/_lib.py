@@ -43,6 +43,9 @@ SIGNATURES = {
                                         vp, ctypes.c_size_t, vp]),
     "spart_run_batch": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int64, ctypes.POINTER(vp), vp, vp, vp, vp, vp,
                                        ctypes.POINTER(SpartMaterialize), vp, ctypes.c_size_t, vp]),
+    "spart_lut_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int64]),
+    "spart_lut_nearest": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int64, ctypes.c_int, vp, ctypes.c_int64, vp, vp, vp, vp,
+                                         vp, ctypes.c_size_t, vp]),
     "spart_profile_enable": (ctypes.c_int, [vp, ctypes.c_int]),
     "spart_profile_read": (ctypes.c_int, [vp, c_dp, ctypes.POINTER(ctypes.c_int)]),
 }

@@ -236,6 +236,29 @@ class Engine:
         _lib.check(self.lib, self.ctx, rc)
         return res
 
+    def lut_nearest(self, lut, obs, weights=None, dtype="float32"):
+        """LUT inversion: for each row of obs (M, nb) the index of the closest row of lut (B, nb) under the
+        weighted squared distance, and that distance.  -> (idx (M,) int64 tensor, cost (M,) tensor)"""
+        torch = self.torch
+        dt = DTYPES[dtype]
+        td = self._tdtype(dt)
+        lut = torch.as_tensor(lut).to(device=self.device, dtype=td).contiguous()
+        obs = torch.as_tensor(obs).to(device=self.device, dtype=td).contiguous()
+        if lut.dim() != 2 or obs.dim() != 2 or lut.shape[1] != obs.shape[1]:
+            raise ValueError("lut (B, nb) and obs (M, nb) must share nb")
+        w = None if weights is None else torch.as_tensor(weights).to(device=self.device, dtype=td).contiguous()
+        B, nb = lut.shape
+        M = obs.shape[0]
+        idx = torch.empty((M,), dtype=torch.int64, device=self.device)
+        cost = torch.empty((M,), dtype=td, device=self.device)
+        n = int(self.lib.spart_lut_workspace_bytes(dt, B, nb, M))
+        ws = torch.empty(max(n, 256), dtype=torch.uint8, device=self.device)
+        rc = self.lib.spart_lut_nearest(self.ctx, dt, B, nb, lut.data_ptr(), M, obs.data_ptr(),
+                                        w.data_ptr() if w is not None else None, idx.data_ptr(), cost.data_ptr(),
+                                        ws.data_ptr(), ctypes.c_size_t(ws.numel()), self._stream())
+        _lib.check(self.lib, self.ctx, rc)
+        return idx, cost
+
     def profile(self, max_calls):
         """bracket the band kernel of the next ``max_calls`` run() calls with HIP events (0 = off)."""
         _lib.check(self.lib, self.ctx, self.lib.spart_profile_enable(self.ctx, int(max_calls)))

@@ -334,3 +334,44 @@ def test_lut_generation_streams_chunks(tmp_path, torch_mod):
     import pandas as pd
     df = pd.read_parquet(pq)
     assert df.shape == (B, 27 + 3 * 13) and abs(df["R_TOC_445"].iloc[5] - ref["R_TOC"][5, 0]) == 0
+
+
+@pytest.mark.parametrize("dtype,nb", [("float32", 13), ("float64", 13), ("float32", 6), ("float32", 21)])
+def test_lut_inversion_matches_brute_force(dtype, nb, torch_mod):
+    """spart_lut_nearest against a numpy brute-force search (weighted and unweighted, ragged sizes, NaN rows)."""
+    from spart_amd import get_engine
+    rng = np.random.default_rng(nb)
+    B, M = 20_011, 777
+    lut = rng.uniform(0.0, 0.6, (B, nb))
+    lut[17] = np.nan                                  # a NaN row must never win
+    obs = lut[rng.integers(18, B, M)] + rng.normal(0, 0.01, (M, nb))
+    obs[:5] = lut[100:105]                            # exact members: cost 0, index recovered
+    eng = get_engine(None, 0)
+    npdt = np.float32 if dtype == "float32" else np.float64
+    for w in (None, rng.uniform(0.5, 2.0, nb)):
+        idx, cost = eng.lut_nearest(lut.astype(npdt), obs.astype(npdt), w, dtype)
+        idx, cost = idx.cpu().numpy(), cost.double().cpu().numpy()
+        L, O = lut.astype(npdt).astype(np.float64), obs.astype(npdt).astype(np.float64)
+        ww = np.ones(nb) if w is None else w.astype(npdt).astype(np.float64)
+        d = np.stack([np.nansum(ww * (L - O[m]) ** 2, axis=1) + np.where(np.isnan(L[:, 0]), np.inf, 0) for m in range(M)])
+        true_idx, true_cost = d.argmin(axis=1), d.min(axis=1)
+        tol = 1e-6 if dtype == "float32" else 1e-12
+        assert np.all(d[np.arange(M), idx] <= true_cost + tol)            # the chosen row is a minimiser (ties aside)
+        assert np.mean(idx == true_idx) > 0.999
+        assert np.max(np.abs(cost - true_cost)) < 10 * tol
+        assert list(idx[:5]) == [100, 101, 102, 103, 104] and np.all(cost[:5] < tol)
+
+
+def test_lut_inversion_recovers_parameters(torch_mod):
+    """End to end: build a LUT with the evaluator, invert noisy copies of some of its rows."""
+    from spart_amd import get_engine, workloads
+    eng = get_engine("Sentinel2A-MSI", 0)
+    P = workloads.lhs_params(200_000, "full", seed=33)
+    out = eng.run(torch_mod.as_tensor(P.T.copy(), device="cuda:0"), "float32")
+    lut = out["R_TOA"].clone()
+    pick = torch_mod.arange(0, 200_000, 997, device="cuda:0")
+    idx, cost = eng.lut_nearest(lut, lut[pick])
+    # float32 evaluates |x|^2 - 2 x.y + |y|^2, so an exact member comes back with a cost of a few ulp of |x|^2
+    assert float((idx == pick).double().mean()) > 0.99 and float(cost.max()) < 1e-5
+    idx64, cost64 = eng.lut_nearest(lut.double(), lut[pick].double(), dtype="float64")
+    assert torch_mod.equal(idx64, pick) and float(cost64.max()) < 1e-14
