@@ -189,14 +189,15 @@ template <typename T> SPART_HD void plate_tau(T K, T& tau, T& u) {
     for (int i = C::GD - 1; i >= 0; --i) g = g * x + C::g(i);
     v = x * (g + x * Mx<T>::log(x));
   } else {
-    T t = Mx<T>::rcp(x);
-    T pn = C::p(C::WD), qn = C::q(C::WD);
+    // P(t)/Q(t) with t = 1/x, written in x (coefficients reversed) so that a single reciprocal is needed:
+    // tau = e^-x * 2 Pr(x) / ((x + 3) Qr(x)),  Pr(x) = x^n P(1/x)
+    T pn = C::p(0), qn = C::q(0);
 #pragma unroll
-    for (int i = C::WD - 1; i >= 0; --i) {
-      pn = pn * t + C::p(i);
-      qn = qn * t + C::q(i);
+    for (int i = 1; i <= C::WD; ++i) {
+      pn = pn * x + C::p(i);
+      qn = qn * x + C::q(i);
     }
-    v = Mx<T>::exp(-x) * (T(2) * t) * pn * Mx<T>::rcp((T(1) + T(3) * t) * qn);
+    v = Mx<T>::exp(-x) * (T(2) * pn) * Mx<T>::rcp((x + T(3)) * qn);
   }
   T w = T(1) - v;
   u = small ? v : w;
@@ -283,8 +284,8 @@ SPART_HD void leaf_band(const BandTab<T>& tb, T cab, T cca, T cdm, T cw, T cs, T
   T Ra = ralf + x * Ta;  // :210
   T t = tb.t12 * c;      // :213
   T r = r12 + x * t;     // :214
-  // 1 - r - t = t12 (1-tau)/(1 - r21 tau);  1 - Ra - Ta = talf (1-tau)/(1 - r21 tau)
-  T gq = u * Mx<T>::rcp(T(1) - x);
+  // 1 - r - t = t12 (1-tau)/(1 - r21 tau);  1 - Ra - Ta = talf (1-tau)/(1 - r21 tau);  1/(1-x) = (1+x)/(1-x^2)
+  T gq = u * (T(1) + x) * inv;
   T a1 = tb.t12 * gq;
   T atop = tb.talf * gq;
   // Stokes system for the N-1 lower layers (:219-230), written in a-1, b-1 and b^-(N-1)
@@ -298,16 +299,16 @@ SPART_HD void leaf_band(const BandTab<T>& tb, T cab, T cca, T cdm, T cw, T cs, T
   T omsq = Mx<T>::one_minus_exp_neg(z);  // 1 - b^-(N-1)
   T omq = omsq * (T(1) + sq);     // 1 - b^-2(N-1)
   T A2 = am1 * (a + T(1));        // a^2 - 1
-  T iden = Mx<T>::rcp(A2 + omq);  // b^-2(N-1) (a^2 b^2(N-1) - 1)
-  T Rsub = a * omq * iden;        // :229
-  T Tsub = sq * A2 * iden;        // :230
-  T asub = am1 * omsq * (a - sq) * iden;  // 1 - Rsub - Tsub
-  // zero absorption (r + t >= 1, :233-235) is the a1 -> 0+ limit of the expressions above:
+  // Rsub = a omq / den, Tsub = sq A2 / den, den = A2 + omq (:229-230 divided by b^2(N-1)); combined with the top
+  // layer (:239-241) everything shares the ONE denominator E = den (1 - Rsub r) = den - a omq r:
+  T aomq = a * omq;
+  T iE = Mx<T>::rcp(A2 + omq - aomq * r);
+  // zero absorption (r + t >= 1, :233-235) is the a1 -> 0+ limit of these expressions:
   // Tsub -> t/(t + (1-t)(N-1)), Rsub -> 1 - Tsub; plate_tau keeps a1 > 0 so no branch is needed.
-  T dd = Mx<T>::rcp(T(1) - Rsub * r);  // :239
-  tran = Ta * Tsub * dd;               // :240
-  refl = Ra + Ta * Rsub * t * dd;      // :241
-  absb = atop + Ta * (asub + Rsub * a1) * dd;
+  T TaE = Ta * iE;
+  tran = TaE * sq * A2;                                   // Ta Tsub / (1 - Rsub r)          (:240)
+  refl = Ra + TaE * aomq * t;                             // Ra + Ta Rsub t / (1 - Rsub r)   (:241)
+  absb = atop + TaE * (am1 * omsq * (a - sq) + aomq * a1);  // 1 - refl - tran, every term >= 0
 }
 
 // ------------------------------------------------------------------------------------------

@@ -42,6 +42,34 @@ __global__ __launch_bounds__(256) void k(float* out, const float* __restrict__ s
 #define OP(x) a0 = __builtin_fmaf(a0, v0, v1);
       OP(a0) OP(a1) OP(a2) OP(a3) OP(a4) OP(a5) OP(a6) OP(a7)
 #undef OP
+    } else if (MODE == 8) { // 8 literal FMAs interleaved with 2 rcp (do transcendentals overlap plain VALU?)
+      a0 = __builtin_fmaf(a0, v0, 0.3183099f); a1 = __builtin_fmaf(a1, v0, 0.3183099f);
+      a6 = __builtin_amdgcn_rcpf(a6);
+      a2 = __builtin_fmaf(a2, v0, 0.3183099f); a3 = __builtin_fmaf(a3, v0, 0.3183099f);
+      a4 = __builtin_fmaf(a4, v0, 0.3183099f); a5 = __builtin_fmaf(a5, v0, 0.3183099f);
+      a7 = __builtin_amdgcn_rcpf(a7);
+      a0 = __builtin_fmaf(a0, v1, 0.5f); a1 = __builtin_fmaf(a1, v1, 0.25f);
+    } else if (MODE == 10) { // 8 FMAs, then the 2 rcp back to back
+      a0 = __builtin_fmaf(a0, v0, 0.3183099f); a1 = __builtin_fmaf(a1, v0, 0.3183099f);
+      a2 = __builtin_fmaf(a2, v0, 0.3183099f); a3 = __builtin_fmaf(a3, v0, 0.3183099f);
+      a4 = __builtin_fmaf(a4, v0, 0.3183099f); a5 = __builtin_fmaf(a5, v0, 0.3183099f);
+      a0 = __builtin_fmaf(a0, v1, 0.5f); a1 = __builtin_fmaf(a1, v1, 0.25f);
+      asm volatile("v_rcp_f32 %0, %0\n\tv_rcp_f32 %1, %1" : "+v"(a6), "+v"(a7));
+    } else if (MODE == 11) { // 32 FMAs then 8 rcp back to back (same ratio, bigger groups)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        a0 = __builtin_fmaf(a0, v0, 0.3183099f); a1 = __builtin_fmaf(a1, v0, 0.3183099f);
+        a2 = __builtin_fmaf(a2, v0, 0.3183099f); a3 = __builtin_fmaf(a3, v0, 0.3183099f);
+        a4 = __builtin_fmaf(a4, v0, 0.3183099f); a5 = __builtin_fmaf(a5, v0, 0.3183099f);
+        a0 = __builtin_fmaf(a0, v1, 0.5f); a1 = __builtin_fmaf(a1, v1, 0.25f);
+      }
+      asm volatile("v_rcp_f32 %0, %0\n\tv_rcp_f32 %1, %1\n\tv_rcp_f32 %0, %0\n\tv_rcp_f32 %1, %1\n\t"
+                   "v_rcp_f32 %0, %0\n\tv_rcp_f32 %1, %1\n\tv_rcp_f32 %0, %0\n\tv_rcp_f32 %1, %1" : "+v"(a6), "+v"(a7));
+    } else if (MODE == 9) { // the same 8 FMAs without the rcps
+      a0 = __builtin_fmaf(a0, v0, 0.3183099f); a1 = __builtin_fmaf(a1, v0, 0.3183099f);
+      a2 = __builtin_fmaf(a2, v0, 0.3183099f); a3 = __builtin_fmaf(a3, v0, 0.3183099f);
+      a4 = __builtin_fmaf(a4, v0, 0.3183099f); a5 = __builtin_fmaf(a5, v0, 0.3183099f);
+      a0 = __builtin_fmaf(a0, v1, 0.5f); a1 = __builtin_fmaf(a1, v1, 0.25f);
     } else if (MODE == 7) { // v_cndmask + v_cmp pairs
 #define OP(x) x = (x > v0) ? v1 : x + s1;
       OP(a0) OP(a1) OP(a2) OP(a3) OP(a4) OP(a5) OP(a6) OP(a7)
@@ -81,5 +109,9 @@ int main() {
   run<5>("exp2", out, sc, blocks);
   run<6>("fma dependent chain", out, sc, blocks);
   run<7>("cmp+cndmask+add", out, sc, blocks);
+  run<9>("8 fma literal (per 8)", out, sc, blocks);
+  run<8>("8 fma literal + 2 rcp (per 8)", out, sc, blocks);
+  run<10>("8 fma, 2 rcp grouped (per 8)", out, sc, blocks);
+  run<11>("32 fma, 8 rcp grouped (per 8; x4 work)", out, sc, blocks);
   return 0;
 }
