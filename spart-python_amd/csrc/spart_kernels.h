@@ -3,8 +3,8 @@
 // Layout: the band axis is mapped onto lanes.  A workgroup of 256 lanes owns
 // 256 consecutive bands and walks a chunk of samples; each lane keeps ITS band's 17 table
 // values in VGPRs for the whole walk (the tables are read from memory once per workgroup,
-// coalesced along the band axis), while the per-sample constants are wave-uniform and
-// arrive through scalar loads from the prelude's workspace.  2001 optical bands + one
+// coalesced along the band axis), while the per-sample constants are wave-uniform and are
+// staged through LDS from the prelude's workspace (broadcast reads into VGPRs).  2001 optical bands + one
 // thermal evaluation (the 161 thermal bands are identical, SPART.py:427-470) fill
 // 2002 of the 2048 lanes of eight workgroups.
 #pragma once
@@ -141,8 +141,21 @@ __global__ __launch_bounds__(TILE) void k_bands(const T* __restrict__ tab, const
   const int64_t s0 = ck * chunk;
   const int64_t s1 = (s0 + chunk < B) ? s0 + chunk : B;
   T sum_so = T(0), sum_do = T(0), sum_sd = T(0), sum_dd = T(0);
-  for (int64_t s = s0; s < s1; ++s) {
-    const T* __restrict__ c = cst + s * NCONST;        // wave-uniform -> scalar loads
+  // Per-sample constants are staged through LDS, 32 samples (6 KB fp32) at a time: one coalesced copy by the
+  // workgroup, then every wave reads sample s's 48 values with wave-uniform ds_read_b128 (a broadcast).  They
+  // land in VGPRs: on gfx950 a VALU op with an SGPR source issues ~1.6x slower than with VGPR / literal sources
+  // (profiles/r1_ubench_valu_issue.txt), and ~60 ops per band use these constants -- the same kernel with
+  // scalar loads (s_load_dwordx8 -> SGPR operands) is 6 % slower.
+  constexpr int SUB = 32;
+  __shared__ __attribute__((aligned(16))) T lds_c[SUB * NCONST];
+  for (int64_t sb = s0; sb < s1; sb += SUB) {
+  const int nsub = (int)((s1 - sb < SUB) ? (s1 - sb) : SUB);
+  __syncthreads();                                     // the previous sub-chunk has been consumed by every wave
+  for (int i = threadIdx.x; i < nsub * NCONST; i += TILE) lds_c[i] = cst[sb * NCONST + i];
+  __syncthreads();
+  for (int si = 0; si < nsub; ++si) {
+    const int64_t s = sb + si;
+    const T* c = lds_c + si * NCONST;                  // uniform LDS address -> broadcast ds_read into VGPRs
     T refl, tran, absb, K;
     leaf_band<T>(tb, c[C_CAB], c[C_CCA], c[C_CDM], c[C_CW], c[C_CS], c[C_CANT], c[C_CBC], c[C_PROT], c[C_NM1], refl,
                  tran, absb, K);
@@ -181,6 +194,7 @@ __global__ __launch_bounds__(TILE) void k_bands(const T* __restrict__ tab, const
         if (mat.gsoil && slot >= 0) mat.gsoil[s * nslot + slot] = rwet;
       }
     }
+  }
   }
   if (FULL) {
     T* bs = bandsum + (ck * (NTILE * TILE) + band) * 4;
