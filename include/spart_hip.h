@@ -79,6 +79,8 @@ typedef struct spart_materialize {
   void *rso, *rdo, *rsd, *rdd; /* (B,2162) sailh.py:224-233                  */
   void *rsoil;                 /* (B,nb) debug column, SPART.py:262-267      */
   void *La;                    /* (B,nb) convolved ET radiance, SPART.py:183 */
+  const void *rdry_in;         /* INPUT, optional: (B,2001) user dry-soil spectra in `dtype` (SoilParametersFromFile,
+                                  bsm.py:42-43, 155-199); params[9..11] (B, lat, lon) may then be NULL */
   void *band_mean;             /* (4,2162) batch means of rso, rdo, rsd, rdd (LUT summary; no reference counterpart) */
   int32_t prune_unused_bands;  /* 0 (default): every one of the 2162 bands of every sample is evaluated and
                                   feeds band_mean's per-chunk sums; 1: bands that no requested output needs

@@ -622,7 +622,7 @@ def pad_soil(refl):
 
 
 def spart_run(P, sensor, tables=None, e1="exp1", pso="quad",
-              rho_thermal=0.01, tau_thermal=0.01, full=False):
+              rho_thermal=0.01, tau_thermal=0.01, full=False, rdry=None):
     """SPART(...).run() for a fresh object per row (SPART.py:162-269).
 
     P : (B, 27) parameter matrix (layout in the module docstring)
@@ -634,7 +634,7 @@ def spart_run(P, sensor, tables=None, e1="exp1", pso="quad",
     leaf, soil, canopy, angles, atm, DOY = P[:, 0:9], P[:, 9:15], P[:, 15:19], P[:, 19:22], P[:, 22:26], P[:, 26]
 
     refl, tran, kchl = prospect_5d(leaf, tables, e1=e1)
-    rwet, rdry = bsm(soil, tables)
+    rwet, rdry = bsm(soil, tables, rdry=rdry)      # rdry given: SoilParametersFromFile branch (bsm.py:42-43)
     rho, tau = pad_leaf(refl, tran, rho_thermal, tau_thermal)
     rs = pad_soil(rwet)
     can = sailh(rho, tau, rs, canopy, angles, pso=pso)

@@ -201,7 +201,8 @@ static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_
     mp.soil_refl = (T*)opt->soil_refl; mp.soil_dry = (T*)opt->soil_refl_dry;
     mp.rso = (T*)opt->rso; mp.rdo = (T*)opt->rdo; mp.rsd = (T*)opt->rsd; mp.rdd = (T*)opt->rdd;
     mp.gsoil = opt->rsoil ? gs : nullptr;
-    mat = mp.leaf_refl || mp.leaf_tran || mp.leaf_kchl || mp.soil_refl || mp.soil_dry || mp.rso || mp.rdo || mp.rsd ||
+    mp.rdry_in = (const T*)opt->rdry_in;
+    mat = mp.rdry_in || mp.leaf_refl || mp.leaf_tran || mp.leaf_kchl || mp.soil_refl || mp.soil_dry || mp.rso || mp.rdo || mp.rsd ||
           mp.rdd || mp.gsoil;
   }
   dim3 grid(xcd_grid(nchunk));
@@ -547,7 +548,8 @@ int spart_run_batch(spart_ctx* ctx, int dtype, int64_t B, const double* const pa
   if (ctx->nb == 0) return fail(ctx, SPART_ERR_NOSENSOR, "spart_run_batch: context has no sensor");
   if (!params || !R_TOC || !R_TOA || !L_TOA) return fail(ctx, SPART_ERR_INVALID, "spart_run_batch: null argument");
   for (int i = 0; i < SPART_NPARAM; ++i)
-    if (!params[i]) return fail(ctx, SPART_ERR_INVALID, "spart_run_batch: params[%d] is null", i);
+    if (!params[i] && !(opt && opt->rdry_in && i >= 9 && i <= 11))   // B, lat, lon are unused with user dry spectra
+      return fail(ctx, SPART_ERR_INVALID, "spart_run_batch: params[%d] is null", i);
   return dtype == SPART_F32
              ? run_impl<float>(ctx, B, params, rho_thermal, tau_thermal, R_TOC, R_TOA, L_TOA, opt, wsp, ws, st)
              : run_impl<double>(ctx, B, params, rho_thermal, tau_thermal, R_TOC, R_TOA, L_TOA, opt, wsp, ws, st);

@@ -110,7 +110,8 @@ template <typename T> __device__ __forceinline__ CanopyPar<T> load_canopy(const 
 
 template <typename T> struct MatPtrs {
   T *leaf_refl, *leaf_tran, *leaf_kchl, *soil_refl, *soil_dry, *rso, *rdo, *rsd, *rdd;
-  T* gsoil;  // (B, nslot) wet soil at the sensor-band slots (debug column rsoil)
+  T* gsoil;         // (B, nslot) wet soil at the sensor-band slots (debug column rsoil)
+  const T* rdry_in; // optional (B, 2001) user dry-soil spectra (SoilParametersFromFile, bsm.py:42-43)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(TILE) void k_bands(const T* __restrict__ tab, const
     T refl, tran, absb, K;
     leaf_band<T>(tb, c[C_CAB], c[C_CCA], c[C_CDM], c[C_CW], c[C_CS], c[C_CANT], c[C_CBC], c[C_PROT], c[C_NM1], refl,
                  tran, absb, K);
-    T rdry = soil_dry<T>(tb, c[C_F1], c[C_F2], c[C_F3]);
+    T rdry = (MAT && mat.rdry_in) ? mat.rdry_in[s * NWL + ti] : soil_dry<T>(tb, c[C_F1], c[C_F2], c[C_F3]);
     T fm[7] = {c[C_FM0], c[C_FM1], c[C_FM2], c[C_FM3], c[C_FM4], c[C_FM5], c[C_FM6]};
     T rwet;
     soil_band<T>(tb, rdry, c[C_WET], fm, c[C_FMSUM], c[C_FILM2], rwet);

@@ -384,8 +384,6 @@ class SPART:
         self.sensorinfo = load_sensor_info(sensor)       # FileNotFoundError for unknown sensors (SPART.py:421-423)
 
     def _columns(self):
-        if getattr(self.soilpar, "rdry_set", False):
-            raise NotImplementedError("SPART.run with user dry-soil spectra: use BSM()/SAILH() stage by stage")
         return (self.leafbio.columns() + self.soilpar.columns() + self.canopy.columns() + self.angles.columns()
                 + self.atm.columns() + [self.DOY])
 
@@ -401,10 +399,11 @@ class SPART:
             fields.append("rsoil")
         if materialize:
             fields += ["leaf_refl", "leaf_tran", "leaf_kchl", "soil_refl", "soil_refl_dry", "rso", "rdo", "rsd", "rdd"]
+        rdry = self.soilpar.rdry if getattr(self.soilpar, "rdry_set", False) else None
         res = eng.run(cols, self.dtype, rho_thermal=self.leafbio.rho_thermal, tau_thermal=self.leafbio.tau_thermal,
-                      materialize=fields)
+                      materialize=fields, rdry=rdry)
         out = {k: _np(v) for k, v in res.items()}
-        scalar = _is_scalar(*cols) and out["R_TOC"].shape[0] == 1
+        scalar = _is_scalar(*[c for c in cols if c is not None]) and out["R_TOC"].shape[0] == 1
         wl = self.sensorinfo["wl_smac"].T[0]
         bands = self.sensorinfo["band_id_smac"]
         # attributes documented at SPART.py:66-81

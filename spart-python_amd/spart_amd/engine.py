@@ -192,7 +192,7 @@ class Engine:
         return dict(zip(SMAC_FIELDS, out))
 
     def run(self, params, dtype="float32", rho_thermal=None, tau_thermal=None, materialize=(), out=None,
-            prune=False):
+            prune=False, rdry=None):
         """SPART(...).run() for every column of ``params`` (SPART.py:162-269).
 
         params : (27, B) float64 device tensor (rows = spart_amd.workloads.PARAM_NAMES) or a list of 27
@@ -201,6 +201,8 @@ class Engine:
         out : optional dict with preallocated 'R_TOC','R_TOA','L_TOA' (B,nb) tensors
         prune : False (default) evaluates all 2162 bands of every sample; True lets the kernel skip bands
                 that no requested output needs (identical columns, much less work)
+        rdry : optional (B, 2001) / (2001,) user dry-soil spectra replacing the GSV mixing (bsm.py:42-43);
+               the B / lat / lon entries of ``params`` are then ignored (may be None in a list)
         """
         torch = self.torch
         dt = DTYPES[dtype]
@@ -212,16 +214,27 @@ class Engine:
             B = P.shape[1]
             cols = [P[i] for i in range(_lib.NPARAM)]
         else:
-            cols, B = self.columns(list(params))
+            plist = [0.0 if (p is None and rdry is not None) else p for p in params]
+            cols, B = self.columns(plist)
+            if rdry is not None:
+                r0 = rdry if torch.is_tensor(rdry) else np.asarray(rdry)
+                nrow = 1 if (r0.ndim == 1 or (r0.ndim == 2 and r0.shape[1] == 1)) else r0.shape[0]
+                if nrow > B:
+                    B = nrow
+                    cols = [c.expand(B).contiguous() if c.numel() == 1 else c for c in cols]
         th = [None if x is None else self.to_f64(x, B) for x in (rho_thermal, tau_thermal)]
         res = out if out is not None else {}
         for k in ("R_TOC", "R_TOA", "L_TOA"):
             if k not in res:
                 res[k] = torch.empty((B, self.nb), dtype=td, device=self.device)
         mat = None
-        if materialize or prune:
+        rd = None
+        if materialize or prune or rdry is not None:
             mat = _lib.SpartMaterialize()
             mat.prune_unused_bands = 1 if prune else 0
+            if rdry is not None:
+                rd = self._spec(rdry, B, _lib.NWL, dt)
+                mat.rdry_in = rd.data_ptr()
             for name in materialize:
                 if name not in MATERIALIZE_FIELDS:
                     raise ValueError(f"unknown materialize field {name}")

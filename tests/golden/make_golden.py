@@ -201,7 +201,31 @@ def gen_e2e():
     np.savez_compressed(os.path.join(HERE, "e2e.npz"), **out)
 
 
+def gen_rdry():
+    """Full chain with user dry-soil spectra (SoilParametersFromFile with an array, bsm.py:155-199, 42-43)."""
+    from SPART.bsm import SoilParametersFromFile
+    wl = np.arange(400, 2401, dtype=np.float64)
+    spectra = np.stack([0.08 + 0.25 * (wl - 400) / 2000 + 0.02 * np.sin(wl / 90.0),
+                        0.35 - 0.1 * np.exp(-((wl - 1900) / 60.0) ** 2) + 0.05 * (wl - 400) / 2000,
+                        np.full_like(wl, 0.2)])
+    rows = [(0, 20.0, "Sentinel2A-MSI"), (1, 45.0, "Sentinel2A-MSI"), (2, 4.0, "Sentinel2A-MSI"), (0, 30.0, "TerraAqua-MODIS")]
+    out = {"spectra": spectra}
+    d = workloads.default_row()[0]
+    for i, (k, smp, sensor) in enumerate(rows):
+        with redirect_stdout(io.StringIO()):
+            sp = SPART.SPART(SoilParametersFromFile(spectra[k][:, None].copy(), smp, 25, 0.015),
+                             LeafBiology(*d[0:7]), CanopyStructure(*d[15:19]),
+                             AtmosphericProperties(d[22], d[23], d[24], Pa=d[25]), Angles(*d[19:22]), sensor, 100)
+            df = sp.run(debug=True)
+        out[f"{i}/spec"] = np.array(k); out[f"{i}/SMp"] = np.array(smp); out[f"{i}/sensor"] = np.array(sensor)
+        for c in ("R_TOC", "R_TOA", "L_TOA", "rsoil"):
+            out[f"{i}/{c}"] = df[c].to_numpy()
+        out[f"{i}/soil_refl"] = sp.soilopt.refl[:, 0]
+    np.savez_compressed(os.path.join(HERE, "rdry.npz"), **out)
+    print("rdry", len(rows))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["prospect", "bsm", "sailh", "smac", "e2e"]
+    which = sys.argv[1:] or ["prospect", "bsm", "sailh", "smac", "e2e", "rdry"]
     for w in which:
         globals()["gen_" + w]()

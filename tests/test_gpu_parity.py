@@ -375,3 +375,28 @@ def test_lut_inversion_recovers_parameters(torch_mod):
     assert float((idx == pick).double().mean()) > 0.99 and float(cost.max()) < 1e-5
     idx64, cost64 = eng.lut_nearest(lut.double(), lut[pick].double(), dtype="float64")
     assert torch_mod.equal(idx64, pick) and float(cost64.max()) < 1e-14
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_user_dry_soil_spectra_full_chain(golden, dtype, torch_mod):
+    """SPART.run with SoilParametersFromFile(array): the fused kernel reads the (B,2001) dry spectra from HBM."""
+    import SPART
+    from spart_amd import get_engine, workloads
+    g = golden["rdry"]
+    for i in range(4):
+        sensor = str(g[f"{i}/sensor"])
+        spec = g["spectra"][int(g[f"{i}/spec"])]
+        soil = SPART.SoilParametersFromFile(spec[:, None].copy(), float(g[f"{i}/SMp"]), 25, 0.015)
+        df = SPART.SPART(soil, SPART.LeafBiology(40, 0.01, 0.02, 0, 10, 10, 1.5), SPART.CanopyStructure(3, -0.35, -0.15, 0.05),
+                         SPART.AtmosphericProperties(0.325, 0.35, 1.41, 1013.25), SPART.Angles(40, 0, 0), sensor, 100,
+                         dtype=dtype).run(debug=True)
+        for k in ("R_TOC", "R_TOA", "L_TOA", "rsoil"):
+            assert rel_err(df[k].to_numpy(), g[f"{i}/{k}"], 1e-3) < TOL[dtype], (i, k)
+    # batched: per-sample spectra, GSV columns absent
+    eng = get_engine("Sentinel2A-MSI", 0)
+    P = workloads.lhs_params(3, "full", seed=1)
+    P[:, 12] = [20.0, 45.0, 4.0]
+    cols = [P[:, j] for j in range(27)]
+    cols[9] = cols[10] = cols[11] = None
+    out = eng.run(cols, dtype, rdry=g["spectra"], materialize=("soil_refl_dry",))
+    assert rel_err(out["soil_refl_dry"].cpu().numpy(), g["spectra"], 1e-3) < 1e-6

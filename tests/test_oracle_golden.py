@@ -98,3 +98,17 @@ def test_known_answer_pins(oracle, tables):
 def test_unknown_sensor(oracle, tables):
     with pytest.raises(FileNotFoundError):
         oracle.sensor_tables(tables, "Sentinel9Z")
+
+
+def test_full_chain_with_user_dry_soil_spectra(oracle, tables, golden):
+    """SoilParametersFromFile with an array (bsm.py:42-43, 155-199) through the whole chain."""
+    from spart_amd_workloads import default_row
+    g = golden["rdry"]
+    for i in range(4):
+        sensor = str(g[f"{i}/sensor"])
+        o = oracle.spart_run(default_row(SMp=float(g[f"{i}/SMp"])), sensor, tables,
+                             rdry=g["spectra"][int(g[f"{i}/spec"])][None], full=True)
+        tol = 5e-7 if sensor.startswith("Sentinel2") else 1e-10
+        for k in ("R_TOC", "R_TOA", "L_TOA", "rsoil"):
+            assert np.max(np.abs(o[k][0] - g[f"{i}/{k}"]) / np.abs(g[f"{i}/{k}"])) < tol, (i, k)
+        assert np.max(np.abs(oracle.pad_soil(o["soil_refl"])[0] - g[f"{i}/soil_refl"])) < 1e-14
