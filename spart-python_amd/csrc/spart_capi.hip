@@ -74,10 +74,15 @@ struct Workspace {
   size_t cst_off, atm_off, g_off, gs_off, bs_off, total;
 };
 
-// samples per workgroup of the band kernels: ~2048 chunk rows when the batch allows it (x 8 tiles =
-// 16k workgroups over 256 CUs), so the per-chunk band sums stay <= 64 MB (fp32) whatever B is
+// samples per workgroup of the band kernels.  Large batches: ~2048 chunk rows (x 8 tiles = 16k workgroups over
+// 256 CUs), so the per-chunk band sums stay <= 64 MB (fp32) whatever B is.  Small batches: at least
+// min(32, B/256) samples per workgroup so that the 17 table loads per lane are amortised while ~2000
+// workgroups remain.
 int pick_chunk(int64_t B) {
   int64_t c = (B + 2047) / 2048;
+  int64_t small = (B + 255) / 256;
+  if (small > 32) small = 32;
+  if (c < small) c = small;
   return (int)(c < 1 ? 1 : c);
 }
 

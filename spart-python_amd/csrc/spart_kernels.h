@@ -101,8 +101,7 @@ template <typename T> __device__ __forceinline__ BandTab<T> load_tab(const T* __
 
 template <typename T> __device__ __forceinline__ CanopyPar<T> load_canopy(const T* __restrict__ c) {
   CanopyPar<T> cp;
-  cp.sdb = c[C_SDB]; cp.sdf = c[C_SDF]; cp.ddb = c[C_DDB]; cp.ddf = c[C_DDF];
-  cp.dob = c[C_DOB]; cp.dof = c[C_DOF]; cp.sob = c[C_SOB]; cp.sof = c[C_SOF];
+  cp.sob = c[C_SOB]; cp.sof = c[C_SOF];
   cp.bf = c[C_BF]; cp.ks = c[C_KS]; cp.ko = c[C_KO]; cp.lai = c[C_LAI];
   cp.tss = c[C_TSS]; cp.too = c[C_TOO]; cp.Z = c[C_Z]; cp.hot = c[C_HOT]; cp.pso2w = c[C_PSO2W];
   return cp;

@@ -335,8 +335,10 @@ template <typename T> SPART_HD T soil_dry(const BandTab<T>& tb, T f1, T f2, T f3
 
 // ------------------------------------------------------------------------------------------
 // SAILH, one band                                                  (sailh.py:142-233)
+// (the six geometric factors sdb..dof of sailh.py:100-105 are (k +- bf)/2, (1 +- bf)/2, (K +- bf)/2; canopy_band
+// works from ks, ko, bf directly -- the prelude still writes them to the constant block for inspection)
 template <typename T> struct CanopyPar {
-  T sdb, sdf, ddb, ddf, dob, dof, sob, sof, bf, ks, ko, lai, tss, too, Z, hot, pso2w;
+  T sob, sof, bf, ks, ko, lai, tss, too, Z, hot, pso2w;
 };
 
 template <typename T>

@@ -29,7 +29,6 @@ static void bands_impl(int64_t B, const double* tab, const double* P, double* ou
     std::memcpy(atm_out + s * NATM, a, sizeof(a));
     std::memcpy(lidf_out + s * NLINCL, li, sizeof(li));
     CanopyPar<T> cp;
-    cp.sdb = c[C_SDB]; cp.sdf = c[C_SDF]; cp.ddb = c[C_DDB]; cp.ddf = c[C_DDF]; cp.dob = c[C_DOB]; cp.dof = c[C_DOF];
     cp.sob = c[C_SOB]; cp.sof = c[C_SOF]; cp.bf = c[C_BF]; cp.ks = c[C_KS]; cp.ko = c[C_KO]; cp.lai = c[C_LAI];
     cp.tss = c[C_TSS]; cp.too = c[C_TOO]; cp.Z = c[C_Z]; cp.hot = c[C_HOT]; cp.pso2w = c[C_PSO2W];
     for (int band = 0; band < NEVAL; ++band) {
