@@ -62,6 +62,16 @@ def load(path=None):
         return _libs[path]
     import torch  # noqa: F401
 
+    if not os.path.exists(path) and path == os.path.abspath(LIB_PATH):
+        try:        # the .so is a build artefact (git-ignored): compile it on first use when hipcc is around
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("_spart_build", os.path.join(HERE, "..", "build.py"))
+            b = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(b)
+            b.build(verbose=True)
+        except Exception as e:      # noqa: BLE001
+            raise RuntimeError(f"{path} is missing and could not be built ({e}); run `python spart-python_amd/build.py` "
+                               "(hipcc, gfx950). spart_amd has no CPU fallback.") from e
     if not os.path.exists(path):
         raise RuntimeError(
             f"{path} is missing: build it with `python spart-python_amd/build.py` "
