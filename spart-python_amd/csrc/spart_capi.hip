@@ -228,15 +228,6 @@ static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_
     HIP_TRY(ctx, hipEventRecord(ctx->ev[ctx->ev_used + 1], st));
     ctx->ev_used += 2;
   }
-  if (mat) {
-    T* padded[] = {mp.leaf_refl, mp.leaf_tran, mp.soil_refl, mp.rso, mp.rdo, mp.rsd, mp.rdd};
-    int64_t n = B * (NWLT - 1);
-    for (T* a : padded)
-      if (a) {
-        hipLaunchKernelGGL((k_fill_thermal<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, B);
-        HIP_TRY(ctx, hipGetLastError());
-      }
-  }
   if (opt && opt->band_mean) {
     if (!full) return fail(ctx, SPART_ERR_INVALID, "spart_run_batch: band_mean needs prune_unused_bands = 0");
     hipLaunchKernelGGL((k_bandmean<T>), dim3((4 * NWLS + 255) / 256), dim3(256), 0, st, (const T*)bsum, nchunk, B,

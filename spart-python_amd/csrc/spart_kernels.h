@@ -178,20 +178,41 @@ __global__ __launch_bounds__(TILE) void k_bands(const T* __restrict__ tab, const
     }
     if (MAT) {
       if (active) {
-        const int64_t o = s * NWLS + band;             // band 2001 = first thermal position
-        if (mat.leaf_refl) mat.leaf_refl[o] = rho;
-        if (mat.leaf_tran) mat.leaf_tran[o] = tau;
-        if (mat.soil_refl) mat.soil_refl[o] = rwet;
-        if (mat.rso) mat.rso[o] = rso;
-        if (mat.rdo) mat.rdo[o] = rdo;
-        if (mat.rsd) mat.rsd[o] = rsd;
-        if (mat.rdd) mat.rdd[o] = rdd;
+        // row pointers are wave-uniform (scalar arithmetic); the lane only adds its 32-bit band offset, so the
+        // stores use the SGPR-base + VGPR-offset form and need no 64-bit VALU address math
+        const int64_t ro = s * NWLS;                   // band 2001 = first thermal position
+        if (mat.leaf_refl) (mat.leaf_refl + ro)[band] = rho;
+        if (mat.leaf_tran) (mat.leaf_tran + ro)[band] = tau;
+        if (mat.soil_refl) (mat.soil_refl + ro)[band] = rwet;
+        if (mat.rso) (mat.rso + ro)[band] = rso;
+        if (mat.rdo) (mat.rdo + ro)[band] = rdo;
+        if (mat.rsd) (mat.rsd + ro)[band] = rsd;
+        if (mat.rdd) (mat.rdd + ro)[band] = rdd;
         if (!thermal) {
-          const int64_t o1 = s * NWL + band;
-          if (mat.leaf_kchl) mat.leaf_kchl[o1] = (K > T(0)) ? divx(c[C_CAB] * tb.kab, K) : T(0);  // prospect_5d.py:197-198
-          if (mat.soil_dry) mat.soil_dry[o1] = rdry;
+          const int64_t r1 = s * NWL;
+          if (mat.leaf_kchl) (mat.leaf_kchl + r1)[band] = (K > T(0)) ? divx(c[C_CAB] * tb.kab, K) : T(0);  // prospect_5d.py:197-198
+          if (mat.soil_dry) (mat.soil_dry + r1)[band] = rdry;
         }
-        if (mat.gsoil && slot >= 0) mat.gsoil[s * nslot + slot] = rwet;
+        if (mat.gsoil && slot >= 0) (mat.gsoil + s * nslot)[slot] = rwet;
+      }
+      // thermal padding (SPART.py:427-470): the wave that holds the thermal evaluation (band 2001) copies it over
+      // bands 2002..2161 of the padded spectra -- 160 values per array, three coalesced stores per lane
+      constexpr int TH_WAVE = (NWL % TILE) / 64, TH_LANE = (NWL % TILE) % 64;
+      if (tile == NTILE - 1 && (int)(threadIdx.x >> 6) == TH_WAVE) {
+        const int l = threadIdx.x & 63;
+        const int64_t ro = s * NWLS + NWL + 1;
+        T* arrs[7] = {mat.leaf_refl, mat.leaf_tran, mat.soil_refl, mat.rso, mat.rdo, mat.rsd, mat.rdd};
+        const T vals[7] = {rho, tau, rwet, rso, rdo, rsd, rdd};
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+          const T v = __shfl(vals[q], TH_LANE, 64);
+          if (arrs[q]) {
+            T* dst = arrs[q] + ro;
+            dst[l] = v;
+            dst[64 + l] = v;
+            if (l < NWLT - 1 - 128) dst[128 + l] = v;
+          }
+        }
       }
     }
   }
@@ -213,16 +234,6 @@ __global__ __launch_bounds__(256) void k_bandmean(const T* __restrict__ bandsum,
   double acc = 0.0;
   for (int64_t c = 0; c < nchunk; ++c) acc += (double)bandsum[(c * (NTILE * TILE) + ev) * 4 + q];
   out[i] = (T)(acc / (double)B);
-}
-
-// copy the thermal evaluation (position 2001) over the other 160 thermal bands
-template <typename T>
-__global__ __launch_bounds__(256) void k_fill_thermal(T* __restrict__ a, int64_t B) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int64_t s = i / (NWLT - 1);
-  int j = (int)(i % (NWLT - 1));
-  if (s >= B) return;
-  a[s * NWLS + NWL + 1 + j] = a[s * NWLS + NWL];
 }
 
 // ------------------------------------------------------------------------------------------
