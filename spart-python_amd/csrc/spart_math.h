@@ -143,9 +143,10 @@ template <> struct SailJ<float> {
   static SPART_HD float poly(float d) {
     return 1.0f + d * (-0.5f + d * (0.166666667f + d * (-0.0416666667f + d * 8.33333333e-3f)));
   }
-  static SPART_HD float j1(float L, float tk, float e1, float d) {  // d = (m - k) L, tk = e^-kL
-    if (::fabsf(d) < 0.06f) return L * tk * poly(d);
-    return L * (tk - e1) * Mx<float>::rcp(d);
+  static SPART_HD bool small(float d) { return ::fabsf(d) < 0.06f; }
+  static SPART_HD float j1(float L, float tk, float e1, float d, float id) {  // d = (m - k) L, tk = e^-kL, id = 1/d
+    if (small(d)) return L * tk * poly(d);
+    return L * (tk - e1) * id;
   }
   static SPART_HD float j2(float L, float tk, float e1, float kpm, float ikpm) {  // kpm = k + m > 0, ikpm = 1/kpm
     float d = kpm * L;
@@ -154,7 +155,8 @@ template <> struct SailJ<float> {
   }
 };
 template <> struct SailJ<double> {
-  static SPART_HD double j1(double L, double tk, double, double d) { return L * tk * phi_fn(d); }
+  static SPART_HD bool small(double) { return false; }
+  static SPART_HD double j1(double L, double tk, double, double d, double) { return L * tk * phi_fn(d); }
   static SPART_HD double j2(double L, double, double, double kpm, double) { return L * phi_fn(kpm * L); }
 };
 
@@ -291,8 +293,9 @@ SPART_HD void leaf_band(const BandTab<T>& tb, T cab, T cca, T cdm, T cw, T cs, T
   // Stokes system for the N-1 lower layers (:219-230), written in a-1, b-1 and b^-(N-1)
   T tt = Mx<T>::fmax(t, Mx<T>::tiny());
   T D = Mx<T>::sqrt((T(1) + r + tt) * (T(1) + r - tt) * (T(1) - r + tt) * a1);  // :219
-  T am1 = (a1 * (T(1) - r + tt) + D) * Mx<T>::rcp(T(2) * r);   // a - 1, a from :222
-  T bm1 = (a1 * (T(1) - tt + r) + D) * Mx<T>::rcp(T(2) * tt);  // b - 1, b from :223
+  T i2rt = Mx<T>::rcp(T(2) * r * tt);                          // 1/(2r) = tt i2rt, 1/(2tt) = r i2rt
+  T am1 = (a1 * (T(1) - r + tt) + D) * (tt * i2rt);            // a - 1, a from :222
+  T bm1 = (a1 * (T(1) - tt + r) + D) * (r * i2rt);             // b - 1, b from :223
   T a = T(1) + am1;
   T z = nm1 * Mx<T>::log1p(bm1);  // (N-1) ln b
   T sq = Mx<T>::exp(-z);          // b^-(N-1)
@@ -318,13 +321,26 @@ SPART_HD void soil_band(const BandTab<T>& tb, T rdry, T wet, const T fm[7], T fm
   T rbac = T(1) - (T(1) - rdry) * (rdry * tb.cbac + T(1) - rdry);  // :110-112
   T tw1 = Mx<T>::exp(-film2 * tb.kw);                              // :122 with k = 1
   // rwet = rdry f0 + sum_k f_k [Rw + (1-Rw)(1-p) x_k/(1 - p x_k)],  x_k = tw1^k rbac   (:123-124)
-  T x = rbac;
+  // The six reciprocals 1/d_k, d_k = 1 - p x_k, come from ONE reciprocal of their product (prefix products
+  // forward, peel-off backward): a v_rcp costs about five plain VALU ops in this instruction mix
+  // (profiles/r1_ubench_valu_issue.txt), the 15 extra multiplies three.
+  T x[6], d[6], pre[6];
+  T xv = rbac;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    xv *= tw1;
+    x[k] = xv;
+    d[k] = T(1) - tb.pw * xv;
+    pre[k] = (k == 0) ? d[0] : pre[k - 1] * d[k];
+  }
+  T q = Mx<T>::rcp(pre[5]);
   T acc = T(0);
 #pragma unroll
-  for (int k = 1; k <= 6; ++k) {
-    x *= tw1;
-    acc += fm[k] * x * Mx<T>::rcp(T(1) - tb.pw * x);
+  for (int k = 5; k >= 1; --k) {
+    acc += fm[k + 1] * x[k] * (q * pre[k - 1]);    // 1/d_k = (prod_{j<k} d_j) / (prod_{j<=k} d_j)
+    q *= d[k];
   }
+  acc += fm[1] * x[0] * q;
   T v = rdry * fm[0] + tb.rw * fmsum16 + (T(1) - tb.rw) * (T(1) - tb.pw) * acc;
   rwet = (wet > T(0)) ? v : rdry;                                  // :102-103
 }
@@ -356,7 +372,13 @@ SPART_HD void canopy_band(const CanopyPar<T>& c, T rho, T tau, T absb, T rs, T& 
   T a = T(1) - sigf;                   // :149
   // m^2 = a^2 - sigb^2 = (a - sigb)(a + sigb), a - sigb = 1 - rho - tau, a + sigb = 1 + 2 Mn   (:150)
   T m = Mx<T>::sqrt(absb * (T(1) + T(2) * Mn));
-  T iam = Mx<T>::rcp(a + m);
+  // three reciprocals from one: 1/(a+m), 1/(ks+m), 1/(ko+m)
+  T apm = a + m, ksm = c.ks + m, kom = c.ko + m;
+  T kk = ksm * kom;
+  T i3 = Mx<T>::rcp(apm * kk);
+  T iam = i3 * kk;
+  T ikk = i3 * apm;
+  T iks = ikk * kom, iko = ikk * ksm;
   T rinf = sigb * iam;                 // == (a - m)/sigb   (:151)
   T rinf2 = rinf * rinf;
   // 1 - rinf = (a - sigb + m)/(a + m) = (absorptance + m)/(a + m): no cancellation for nearly
@@ -365,12 +387,14 @@ SPART_HD void canopy_band(const CanopyPar<T>& c, T rho, T tau, T absb, T rs, T& 
   T L = c.lai;
   // J1(-1) = (e^-mL - e^-kL)/(k - m) = L e^-kL phi((m-k)L)   (:154-170, 180-183)
   T e1 = Mx<T>::exp(-m * L);           // :185-189
-  T J1k = SailJ<T>::j1(L, c.tss, e1, (m - c.ks) * L);
-  T J1K = SailJ<T>::j1(L, c.too, e1, (m - c.ko) * L);
+  T d1 = (m - c.ks) * L, d2 = (m - c.ko) * L;
+  T d1s = SailJ<T>::small(d1) ? T(1) : d1, d2s = SailJ<T>::small(d2) ? T(1) : d2;   // (the Taylor branch needs no 1/d)
+  T idd = Mx<T>::rcp(d1s * d2s);
+  T J1k = SailJ<T>::j1(L, c.tss, e1, d1, idd * d2s);
+  T J1K = SailJ<T>::j1(L, c.too, e1, d2, idd * d1s);
   // J2(0) = (1 - e^-kL e^-mL)/(k + m) = L phi((k+m)L)        (:172-177)
-  T iks = Mx<T>::rcp(c.ks + m), iko = Mx<T>::rcp(c.ko + m);
-  T J2k = SailJ<T>::j2(L, c.tss, e1, c.ks + m, iks);
-  T J2K = SailJ<T>::j2(L, c.too, e1, c.ko + m, iko);
+  T J2k = SailJ<T>::j2(L, c.tss, e1, ksm, iks);
+  T J2K = SailJ<T>::j2(L, c.too, e1, kom, iko);
   T ome2 = T(1) - e1 * e1;
   T re = rinf * e1;
   T i1 = Mx<T>::rcp(omr2 * (T(1) + rinf2));  // sic: 1/(1 - rinf2**2) (:189)
