@@ -113,9 +113,57 @@ template <> struct Mx<double> {
   static SPART_HD double exp(double x) { return ::exp(x); }
   static SPART_HD double log(double x) { return ::log(x); }
   static SPART_HD double sqrt(double x) { return ::sqrt(x); }
-  static SPART_HD double rcp(double x) { return 1.0 / x; }
-  static SPART_HD double log1p(double x) { return ::log1p(x); }
-  static SPART_HD double one_minus_exp_neg(double z) { return -::expm1(-z); }
+  // reciprocal: v_rcp_f64 refined by two Newton steps (~1 ulp for normal arguments, 5 instructions) instead of
+  // the ~12-instruction IEEE division sequence; the host build divides
+  static SPART_HD double rcp(double x) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(SPART_FAST_MATH)
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return r;
+#else
+    return 1.0 / x;
+#endif
+  }
+  // ln(1+x), x >= 0: 2 atanh(x/(2+x)) series below 0.1 (s <= 0.048, s^15/15 < 1e-21), log(1+x) above
+  // (whose rounding of 1+x costs at most 1e-16/0.1 relative)
+  static SPART_HD double log1p(double x) {
+#if defined(SPART_FAST_MATH)
+    if (x < 0.1) {
+      double s = x * rcp(2.0 + x), s2 = s * s;
+      double p = 1.0 / 13.0;
+      p = p * s2 + 1.0 / 11.0;
+      p = p * s2 + 1.0 / 9.0;
+      p = p * s2 + 1.0 / 7.0;
+      p = p * s2 + 0.2;
+      p = p * s2 + 1.0 / 3.0;
+      p = p * s2 + 1.0;
+      return 2.0 * s * p;
+    }
+    return ::log(1.0 + x);
+#else
+    return ::log1p(x);
+#endif
+  }
+  // 1 - e^-z, z >= 0: Taylor below 0.02 (z^9/9! < 2e-21), direct above (cancellation <= 1e-16/0.02 relative)
+  static SPART_HD double one_minus_exp_neg(double z) {
+#if defined(SPART_FAST_MATH)
+    if (z < 0.02) {
+      double p = -1.0 / 40320.0;
+      p = p * z + 1.0 / 5040.0;
+      p = p * z - 1.0 / 720.0;
+      p = p * z + 1.0 / 120.0;
+      p = p * z - 1.0 / 24.0;
+      p = p * z + 1.0 / 6.0;
+      p = p * z - 0.5;
+      p = p * z + 1.0;
+      return z * p;
+    }
+    return 1.0 - ::exp(-z);
+#else
+    return -::expm1(-z);
+#endif
+  }
   static SPART_HD double expm1(double x) { return ::expm1(x); }
   static SPART_HD double fabs(double x) { return ::fabs(x); }
   static SPART_HD double fmax(double a, double b) { return ::fmax(a, b); }
@@ -155,9 +203,20 @@ template <> struct SailJ<float> {
   }
 };
 template <> struct SailJ<double> {
-  static SPART_HD bool small(double) { return false; }
-  static SPART_HD double j1(double L, double tk, double, double d, double) { return L * tk * phi_fn(d); }
-  static SPART_HD double j2(double L, double, double, double kpm, double) { return L * phi_fn(kpm * L); }
+  // |d| < 2e-3: Taylor polynomial of phi to d^5 (next term d^6/5040 < 2e-20); outside, the difference of
+  // exponentials loses at most 1e-16/2e-3 relative
+  static SPART_HD double poly(double d) {
+    return 1.0 + d * (-0.5 + d * (1.0 / 6.0 + d * (-1.0 / 24.0 + d * (1.0 / 120.0 - d * (1.0 / 720.0)))));
+  }
+  static SPART_HD bool small(double d) { return ::fabs(d) < 2e-3; }
+  static SPART_HD double j1(double L, double tk, double e1, double d, double id) {
+    if (small(d)) return L * tk * poly(d);
+    return L * (tk - e1) * id;
+  }
+  static SPART_HD double j2(double L, double tk, double e1, double kpm, double ikpm) {
+    double d = kpm * L;
+    return (d < 2e-3) ? L * poly(d) : (1.0 - tk * e1) * ikpm;
+  }
 };
 
 // ------------------------------------------------------------------------------------------
