@@ -322,8 +322,10 @@ static_assert(NCONST == 48, "constant block is 48 values");
 
 // per-sample atmosphere scalars (double), read by the sensor-band kernel
 enum AtmIdx {
-  A_US = 0, A_UV, A_M, A_PEQ, A_PA, A_AOT, A_UO3, A_UH2O, A_CKSI, A_KSID, A_LAF, A_RSV,
-  NATM  // 12
+  A_US = 0, A_UV, A_M, A_PEQ, A_PA, A_AOT, A_UO3, A_UH2O, A_CKSI, A_KSID, A_LAF,
+  A_LOGPEQ, A_LOGM, A_LOGO3M, A_LOGH2OM,   // ln Peq, ln m, ln(uo3 m), ln(uh2o m): x^n is evaluated as exp(n ln x)
+  A_RSV,
+  NATM  // 16
 };
 
 // ------------------------------------------------------------------------------------------
@@ -763,6 +765,10 @@ SPART_HD void sample_prelude(const double* p /*[27]*/, double rho_th, double tau
   atm[A_UH2O] = p[24];
   atm[A_CKSI] = cksi;
   atm[A_KSID] = crd * ::acos(cksi);
+  atm[A_LOGPEQ] = ::log(atm[A_PEQ]);
+  atm[A_LOGM] = ::log(atm[A_M]);
+  atm[A_LOGO3M] = ::log(p[23] * atm[A_M]);
+  atm[A_LOGH2OM] = ::log(p[24] * atm[A_M]);
   double b = 2.0 * PI * p[26] / 365.0;
   double corr = 1.00011 + 0.034221 * ::cos(b) + 0.00128 * ::sin(b) + 0.000719 * ::cos(2.0 * b) +
                 0.000077 * ::sin(2.0 * b);
@@ -786,22 +792,26 @@ enum CoefRow {
 
 SPART_HD SmacOut smac_band(const double* atm, const double* coef, int cs) {
   auto C = [&](int r) { return coef[(size_t)r * cs]; };
+  using Md = Mx<double>;
   double us = atm[A_US], uv = atm[A_UV], m = atm[A_M], Peq = atm[A_PEQ], Pa = atm[A_PA];
-  double taup550 = atm[A_AOT], uo3 = atm[A_UO3], uh2o = atm[A_UH2O], cksi = atm[A_CKSI], ksiD = atm[A_KSID];
+  double taup550 = atm[A_AOT], cksi = atm[A_CKSI], ksiD = atm[A_KSID];
+  double lpeq = atm[A_LOGPEQ], lm = atm[A_LOGM];
+  double ius = Md::rcp(us), iuv = Md::rcp(uv);
   double taup = C(K_A0TAUP) + C(K_A1TAUP) * taup550;  // :103
-  // gaseous transmittances t = exp(a (u m)^n), u = Peq^p (:105-119).  A gas whose coefficient a is zero in
-  // this band has t = exp(0) = 1 exactly (most of CO, CH4, NO2, O2, CO2 in most bands): its two pow/exp
-  // calls are skipped, which leaves the product below bit-identical.
-  auto gas = [&](int ka, int kn, double um) -> double {
+  // gaseous transmittances t = exp(a (u m)^n), u = Peq^p (:105-119), with x^n evaluated as exp(n ln x) from the
+  // per-sample logarithms (arguments are positive; ln 0 = -inf gives 0^n = 0 as numpy does).  A gas whose
+  // coefficient a is zero in this band has t = exp(0) = 1 exactly (most of CO, CH4, NO2, O2, CO2 in most
+  // bands): it is skipped, which leaves the product below bit-identical.
+  auto gas = [&](int ka, int kn, double lum) -> double {
     double av = C(ka);
-    return (av != 0.0) ? ::exp(av * ::pow(um, C(kn))) : 1.0;
+    return (av != 0.0) ? ::exp(av * ::exp(C(kn) * lum)) : 1.0;
   };
   auto pgas = [&](int ka, int kn, int kp) -> double {
     double av = C(ka);
-    return (av != 0.0) ? ::exp(av * ::pow(::pow(Peq, C(kp)) * m, C(kn))) : 1.0;
+    return (av != 0.0) ? ::exp(av * ::exp(C(kn) * (C(kp) * lpeq + lm))) : 1.0;
   };
-  double to3 = gas(K_AO3, K_NO3, uo3 * m);
-  double th2o = gas(K_AH2O, K_NH2O, uh2o * m);
+  double to3 = gas(K_AO3, K_NO3, atm[A_LOGO3M]);
+  double th2o = gas(K_AH2O, K_NH2O, atm[A_LOGH2OM]);
   double to2 = pgas(K_AO2, K_NO2, K_PO2);
   double tco2 = pgas(K_ACO2, K_NCO2, K_PCO2);
   double tch4 = pgas(K_ACH4, K_NCH4, K_PCH4);
@@ -810,45 +820,51 @@ SPART_HD SmacOut smac_band(const double* atm, const double* coef, int cs) {
   SmacOut o;
   o.Tg = th2o * to3 * to2 * tco2 * tch4 * tco * tno2;  // :119
   o.Ra_dd = C(K_A0S) * Peq + C(K_A3S) + C(K_A1S) * taup550 + C(K_A2S) * taup550 * taup550;  // :122
-  o.Ta_s = C(K_A0T) + C(K_A1T) * taup550 / us + (C(K_A2T) * Peq + C(K_A3T)) / (1.0 + us);  // :125
-  o.Ta_o = C(K_A0T) + C(K_A1T) * taup550 / uv + (C(K_A2T) * Peq + C(K_A3T)) / (1.0 + uv);  // :126
+  double tP = C(K_A2T) * Peq + C(K_A3T);
+  o.Ta_s = C(K_A0T) + C(K_A1T) * taup550 * ius + tP * Md::rcp(1.0 + us);  // :125
+  o.Ta_o = C(K_A0T) + C(K_A1T) * taup550 * iuv + tP * Md::rcp(1.0 + uv);  // :126
   double taur = C(K_TAUR);
+  double iusuv = ius * iuv;
   double ray_phase = 0.7190443 * (1.0 + (cksi * cksi)) + 0.0412742;  // :141
-  double ray_ref = (taur * ray_phase) / (4.0 * us * uv);             // :142
+  double ray_ref = (taur * ray_phase) * (0.25 * iusuv);              // :142
   ray_ref = ray_ref * Pa / 1013.25;                                  // :143
   double taurz = taur * Peq;                                         // :144
   double aer_phase = C(K_A0P) + C(K_A1P) * ksiD + C(K_A2P) * ksiD * ksiD + C(K_A3P) * ksiD * ksiD * ksiD +
                      C(K_A4P) * (ksiD * ksiD) * (ksiD * ksiD);  // :146-148
   double wo = C(K_WO), gc = C(K_GC);
-  double ak2 = (1.0 - wo) * (3.0 - wo * 3.0 * gc);  // :149-150
+  double g3 = 3.0 - wo * 3.0 * gc;
+  double ig3 = Md::rcp(g3);
+  double ak2 = (1.0 - wo) * g3;  // :149-150
   double ak = ::sqrt(ak2);
-  double e = -3.0 * us * us * wo / (4.0 * (1.0 - ak2 * us * us));  // :153-157
-  double f = -(1.0 - wo) * 3.0 * gc * us * us * wo / (4.0 * (1.0 - ak2 * us * us));
-  double dp = e / (3.0 * us) + us * f;
+  double idus = Md::rcp(1.0 - ak2 * us * us);
+  double e = -3.0 * us * us * wo * 0.25 * idus;  // :153-157
+  double f = -(1.0 - wo) * 3.0 * gc * us * us * wo * 0.25 * idus;
+  double dp = e * ius * (1.0 / 3.0) + us * f;
   double d = e + f;
-  double b = 2.0 * ak / (3.0 - wo * 3.0 * gc);
-  double eak = ::exp(ak * taup), emak = ::exp(-ak * taup);
+  double b = 2.0 * ak * ig3;
+  double eak = ::exp(ak * taup), emak = Md::rcp(eak);
   double delta = eak * (1.0 + b) * (1.0 + b) - emak * (1.0 - b) * (1.0 - b);  // :158
-  double ww = wo / 4.0;
-  double ss = us / (1.0 - ak2 * us * us);
+  double ww = wo * 0.25;
+  double ss = us * idus;
   double q1 = 2.0 + 3.0 * us + (1.0 - wo) * 3.0 * gc * us * (1.0 + 2.0 * us);
   double q2 = 2.0 - 3.0 * us - (1.0 - wo) * 3.0 * gc * us * (1.0 - 2.0 * us);
-  double q3 = q2 * ::exp(-taup / us);
-  double c1 = ((ww * ss) / delta) * (q1 * eak * (1.0 + b) + q3 * (1.0 - b));   // :164
-  double c2 = -((ww * ss) / delta) * (q1 * emak * (1.0 - b) + q3 * (1.0 + b));  // :165
-  double cp1 = c1 * ak / (3.0 - wo * 3.0 * gc);
-  double cp2 = -c2 * ak / (3.0 - wo * 3.0 * gc);
-  double z = d - wo * 3.0 * gc * uv * dp + wo * aer_phase / 4.0;  // :168-173
+  double q3 = q2 * ::exp(-taup * ius);
+  double wsd = ww * ss * Md::rcp(delta);
+  double c1 = wsd * (q1 * eak * (1.0 + b) + q3 * (1.0 - b));    // :164
+  double c2 = -wsd * (q1 * emak * (1.0 - b) + q3 * (1.0 + b));  // :165
+  double cp1 = c1 * ak * ig3;
+  double cp2 = -c2 * ak * ig3;
+  double z = d - wo * 3.0 * gc * uv * dp + wo * aer_phase * 0.25;  // :168-173
   double x = c1 - wo * 3.0 * gc * uv * cp1;
   double y = c2 - wo * 3.0 * gc * uv * cp2;
-  double aa1 = uv / (1.0 + ak * uv);
-  double aa2 = uv / (1.0 - ak * uv);
-  double aa3 = us * uv / (us + uv);
-  double aer_ref1 = x * aa1 * (1.0 - ::exp(-taup / aa1));  // :175-179
-  double aer_ref2 = y * aa2 * (1.0 - ::exp(-taup / aa2));
-  double aer_ref3 = z * aa3 * (1.0 - ::exp(-taup / aa3));
-  double aer_ref = (aer_ref1 + aer_ref2 + aer_ref3) / (us * uv);
-  double rr = taur * ray_phase / (us * uv);
+  // aa1 = uv/(1 + ak uv), aa2 = uv/(1 - ak uv), aa3 = us uv/(us + uv); taup/aa_i needs no division
+  double n1 = 1.0 + ak * uv, n2 = 1.0 - ak * uv, n3 = us + uv;
+  double aa1 = uv * Md::rcp(n1), aa2 = uv * Md::rcp(n2), aa3 = us * uv * Md::rcp(n3);
+  double aer_ref1 = x * aa1 * (1.0 - ::exp(-taup * n1 * iuv));  // :175-179
+  double aer_ref2 = y * aa2 * (1.0 - ::exp(-taup * n2 * iuv));
+  double aer_ref3 = z * aa3 * (1.0 - ::exp(-taup * n3 * iusuv));
+  double aer_ref = (aer_ref1 + aer_ref2 + aer_ref3) * iusuv;
+  double rr = taur * ray_phase * iusuv;
   double Res_ray = C(K_RESR1) + C(K_RESR2) * rr + C(K_RESR3) * (rr * rr);  // :182-186
   double ta = taup * m * cksi;
   double Res_aer = (C(K_RESA1) + C(K_RESA2) * ta + C(K_RESA3) * (ta * ta)) + C(K_RESA4) * (ta * ta * ta);  // :189-191
@@ -856,8 +872,8 @@ SPART_HD SmacOut smac_band(const double* atm, const double* coef, int cs) {
   double tt = tautot * m * cksi;
   double Res_6s = (C(K_REST1) + C(K_REST2) * tt + C(K_REST3) * (tt * tt)) + C(K_REST4) * (tt * tt * tt);  // :196-198
   o.Ra_so = ray_ref - Res_ray + aer_ref - Res_aer + Res_6s;  // :201
-  o.Ta_ss = ::exp(-tautot / us);                             // :204-207
-  o.Ta_oo = ::exp(-tautot / uv);
+  o.Ta_ss = ::exp(-tautot * ius);                            // :204-207
+  o.Ta_oo = ::exp(-tautot * iuv);
   o.Ta_sd = o.Ta_s - o.Ta_ss;
   o.Ta_do = o.Ta_o - o.Ta_oo;
   return o;

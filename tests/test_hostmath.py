@@ -40,7 +40,7 @@ def run_chain(hm, tab, oracle, tables, P, sensor, dtype):
     P = np.ascontiguousarray(P, dtype=np.float64)
     B = P.shape[0]
     out = np.zeros((B, 2002, 10))
-    atm = np.zeros((B, 12))
+    atm = np.zeros((B, 16))
     lidf = np.zeros((B, 13))
     hm.hm_bands(ctypes.c_int(dtype), ctypes.c_int64(B), dp(tab), dp(P), dp(out), dp(atm), dp(lidf))
     se = oracle.sensor_tables(tables, sensor)
