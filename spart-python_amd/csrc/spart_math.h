@@ -542,24 +542,33 @@ SPART_HD void leaf_angles(double a, double b, double lidf[NLINCL]) {
   }
 }
 
-// _volscatt for one leaf inclination (sailh.py:401-446)
-SPART_HD void volscatt1(double sin_tts, double cos_tts, double sin_tto, double cos_tto, double psi_rad, double sin_l,
-                        double cos_l, double& chi_s, double& chi_o, double& frho, double& ftau) {
-  double cos_psi = ::cos(psi_rad);
+// _volscatt for one leaf inclination (sailh.py:401-446).  Only the two arccosines are evaluated as such: the
+// sines / cosines the reference takes of bts, bto, bt1, bt2, bt3 follow algebraically, because
+// cos bts = -Cs/As (sin >= 0 on [0, pi]), delta1 = |bts - bto|, delta2 = pi - |bts + bto - pi|, and
+// (bt1, bt2, bt3) is (min, median, max) of {psi, delta1, delta2} (delta1 <= delta2 always).
+SPART_HD void volscatt1(double sin_tts, double cos_tts, double sin_tto, double cos_tto, double psi_rad,
+                        double sin_psi, double cos_psi, double sin_l, double cos_l, double& chi_s, double& chi_o,
+                        double& frho, double& ftau) {
   double Cs = cos_l * cos_tts, Ss = sin_l * sin_tts;
   double Co = cos_l * cos_tto, So = sin_l * sin_tto;
   double As = ::fmax(Ss, Cs), Ao = ::fmax(So, Co);
-  double bts = ::acos(-Cs / As), bto = ::acos(-Co / Ao);
-  chi_o = 2.0 / PI * ((bto - PI / 2) * Co + ::sin(bto) * So);
-  chi_s = 2.0 / PI * ((bts - PI / 2) * Cs + ::sin(bts) * Ss);
+  double cbs = -Cs / As, cbo = -Co / Ao;                         // cos bts, cos bto
+  double bts = ::acos(cbs), bto = ::acos(cbo);
+  double sbs = ::sqrt(::fmax(0.0, 1.0 - cbs * cbs)), sbo = ::sqrt(::fmax(0.0, 1.0 - cbo * cbo));
+  chi_o = 2.0 / PI * ((bto - PI / 2) * Co + sbo * So);
+  chi_s = 2.0 / PI * ((bts - PI / 2) * Cs + sbs * Ss);
   double delta1 = ::fabs(bts - bto);
   double delta2 = PI - ::fabs(bts + bto - PI);
-  double Tot = psi_rad + delta1 + delta2;
-  double bt1 = ::fmin(psi_rad, delta1);
-  double bt3 = ::fmax(psi_rad, delta2);
-  double bt2 = Tot - bt1 - bt3;
+  double cd1 = cbs * cbo + sbs * sbo, sd1 = ::fabs(sbs * cbo - cbs * sbo);   // cos / sin delta1
+  double cd2 = cbs * cbo - sbs * sbo, sd2 = ::fabs(sbs * cbo + cbs * sbo);   // cos / sin delta2
+  // bt1 = min(psi, delta1), bt3 = max(psi, delta2), bt2 = the remaining one (:429-431)
+  bool p_lt_d1 = psi_rad < delta1, p_gt_d2 = psi_rad > delta2;
+  double cbt1 = p_lt_d1 ? cos_psi : cd1;
+  double cbt3 = p_gt_d2 ? cos_psi : cd2;
+  double bt2 = p_lt_d1 ? delta1 : (p_gt_d2 ? delta2 : psi_rad);
+  double sbt2 = p_lt_d1 ? sd1 : (p_gt_d2 ? sd2 : sin_psi);
   double T1 = 2.0 * Cs * Co + Ss * So * cos_psi;
-  double T2 = ::sin(bt2) * (2.0 * As * Ao + Ss * So * ::cos(bt1) * ::cos(bt3));
+  double T2 = sbt2 * (2.0 * As * Ao + Ss * So * cbt1 * cbt3);
   double Jmin = bt2 * T1 - T2;
   double Jplus = (PI - bt2) * T1 + T2;
   frho = ::fmax(0.0, Jplus / (2.0 * PI * PI));
@@ -586,7 +595,7 @@ struct PsoFn {
   bool hot;  // dso == 0
   SPART_HD double operator()(double x) const {
     if (hot) return ::exp(A * x);  // A holds (K+k-sqrt(Kk)) LAI in this branch (:127)
-    return ::exp(A * x + C * (-::expm1(alpha * x)));  // :121-125
+    return ::exp(A * x + C * Mx<double>::one_minus_exp_neg(-alpha * x));  // :121-125 (x <= 0)
   }
 };
 
@@ -641,7 +650,7 @@ SPART_HD void hotspot_integrals(double K, double k, double LAI, double q, double
   }
   tot += gl_panel<FAST>(f, lo, 0.0);
   int_canopy = tot;
-  pso2w = gl_panel<false>(f, -1.0 - dx, -1.0) / dx;
+  pso2w = gl_panel<FAST>(f, -1.0 - dx, -1.0) / dx;   // smooth there: rate * dx/2 <= 2 unless rate > 240
 }
 
 // ------------------------------------------------------------------------------------------
@@ -707,7 +716,9 @@ SPART_HD void sample_prelude(const double* p /*[27]*/, double rho_th, double tau
   double psi_rad = psi * d2r;
   double sin_tts = ::sin(tts * d2r), cos_tts = ::cos(tts * d2r), tan_tts = ::tan(tts * d2r);
   double sin_tto = ::sin(tto * d2r), cos_tto = ::cos(tto * d2r), tan_tto = ::tan(tto * d2r);
-  double dso = ::sqrt(tan_tts * tan_tts + tan_tto * tan_tto - 2.0 * tan_tts * tan_tto * ::cos(psi_rad));  // :78
+  double sin_psi, cos_psi;
+  ::sincos(psi_rad, &sin_psi, &cos_psi);
+  double dso = ::sqrt(tan_tts * tan_tts + tan_tto * tan_tto - 2.0 * tan_tts * tan_tto * cos_psi);  // :78
   double ks = 0, ko = 0, bf = 0, sob = 0, sof = 0, Fprev = 0;
   for (int i = 0; i < NLINCL; ++i) {
     double F = (i < NLINCL - 1) ? (FAST ? lidf_dcum_newton(LIDFa, LIDFb, lidf_theta(i))
@@ -719,7 +730,7 @@ SPART_HD void sample_prelude(const double* p /*[27]*/, double rho_th, double tau
     double tl = lidf_litab(i) * d2r;
     double sl = ::sin(tl), cl = ::cos(tl);
     double chi_s, chi_o, frho, ftau;
-    volscatt1(sin_tts, cos_tts, sin_tto, cos_tto, psi_rad, sl, cl, chi_s, chi_o, frho, ftau);  // :81-83
+    volscatt1(sin_tts, cos_tts, sin_tto, cos_tto, psi_rad, sin_psi, cos_psi, sl, cl, chi_s, chi_o, frho, ftau);  // :81-83
     ks += chi_s / cos_tts * li;                                                               // :85, 93
     ko += chi_o / cos_tto * li;                                                               // :86, 94
     bf += cl * cl * li;                                                                       // :90, 95
