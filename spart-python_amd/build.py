@@ -17,7 +17,7 @@ OUT = os.path.join(HERE, "libspart_hip.so")
 # -fno-slp-vectorize: hipcc's SLP pass packs independent fp32 ops into v_pk_mul/v_pk_fma, which issue at
 # half rate on gfx950 and block FMA contraction; the VALU-bound band kernel is 12 % faster without it
 # (profiles/README.md)
-FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-fno-slp-vectorize"]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-fno-slp-vectorize", "-ldl"]
 
 
 def hipcc():

@@ -2,10 +2,12 @@
 // derivation, workspace carving, kernel launches).  No torch types, no allocation on the
 // call path (graph-capturable), caller owns every buffer.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -54,6 +56,40 @@ static int fail(const spart_ctx* ctx, int code, const char* fmt, ...) {
   } while (0)
 
 namespace {
+
+// Optional ROCTX ranges around the stages of spart_run_batch (the counterpart of the reference's NVTX
+// annotations, SPART.py:191-227).  Never a hard dependency: the marker library is looked up with dlopen
+// only when SPART_ROCTX=1 is set, and its absence is silent.
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    const char* e = std::getenv("SPART_ROCTX");
+    if (!e || e[0] != '1') return;
+    for (const char* name : {"librocprofiler-sdk-roctx.so", "libroctx64.so"}) {
+      void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (!h) continue;
+      push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+      pop = (int (*)())dlsym(h, "roctxRangePop");
+      if (push && pop) return;
+      push = nullptr;
+      pop = nullptr;
+    }
+  }
+};
+Roctx& roctx() {
+  static Roctx r;
+  return r;
+}
+struct Range {
+  bool on;
+  explicit Range(const char* name) : on(roctx().push != nullptr) {
+    if (on) roctx().push(name);
+  }
+  ~Range() {
+    if (on) roctx().pop();
+  }
+};
 
 struct DeviceGuard {
   int prev = -1;
@@ -193,8 +229,13 @@ static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_
   double* atm = (double*)(wsp + ws.atm_off);
   T* G = (T*)(wsp + ws.g_off);
   T* gs = (T*)(wsp + ws.gs_off);
-  int rc = launch_prelude<T>(ctx, pp, PRE_ALL, B, cst, atm, nullptr, st);
+  int rc;
+  {
+    Range r("SPART prelude (geometry, LIDF, hot spot, soil factors)");
+    rc = launch_prelude<T>(ctx, pp, PRE_ALL, B, cst, atm, nullptr, st);
+  }
   if (rc) return rc;
+  Range rb("SPART bands + sensor (BSM, PROSPECT, SAILH | interp, SMAC, TOC->TOA)");
   int chunk = pick_chunk(B);
   int64_t nchunk = (B + chunk - 1) / chunk;
   const T* tab = sizeof(T) == 4 ? (const T*)ctx->tabF : (const T*)ctx->tabD;
