@@ -24,6 +24,7 @@ struct spart_ctx {
   double* Ea = nullptr;     // (NWL)
   int nb = 0, nslot = 0;
   int* need_slot = nullptr;  // (2048) eval index -> slot or -1
+  int* slot_band = nullptr;  // (nslot) slot -> eval index (pruned mode)
   int* slot0 = nullptr;      // (nb)
   int* slot1 = nullptr;      // (nb)
   double* frac = nullptr;    // (nb)
@@ -262,7 +263,11 @@ static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_
   if (mat && full) SPART_LAUNCH_BANDS(true, true);
   else if (mat) SPART_LAUNCH_BANDS(true, false);
   else if (full) SPART_LAUNCH_BANDS(false, true);
-  else SPART_LAUNCH_BANDS(false, false);
+  else {   // columns only, pruning allowed: evaluate just the sensor's bands
+    int64_t n = B * ctx->nslot;
+    hipLaunchKernelGGL((k_bands_pruned<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, tab, (const T*)cst,
+                       (const int*)ctx->slot_band, ctx->nslot, G, B);
+  }
 #undef SPART_LAUNCH_BANDS
   HIP_TRY(ctx, hipGetLastError());
   if (prof) {
@@ -344,6 +349,7 @@ int spart_ctx_destroy(spart_ctx* ctx) {
   if (!ctx) return SPART_OK;
   DeviceGuard g(ctx->device);
   (void)hipFree(ctx->tabF); (void)hipFree(ctx->tabD); (void)hipFree(ctx->Ea); (void)hipFree(ctx->need_slot);
+  (void)hipFree(ctx->slot_band);
   (void)hipFree(ctx->slot0); (void)hipFree(ctx->slot1); (void)hipFree(ctx->frac); (void)hipFree(ctx->coef);
   (void)hipFree(ctx->econv);
   for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
@@ -427,6 +433,10 @@ int spart_ctx_create(spart_ctx** out, int device, const spart_tables* t) {
       fr[j] = f;
     }
     ctx->nslot = nslot;
+    std::vector<int> sband(nslot > 0 ? nslot : 1, 0);
+    for (int ev = 0; ev < NTILE * TILE; ++ev)
+      if (need[ev] >= 0) sband[need[ev]] = ev;
+    if ((rc = upload(ctx, &ctx->slot_band, sband))) { std::snprintf(g_err, 512, "%s", ctx->err); spart_ctx_destroy(ctx); return rc; }
     std::vector<double> coef(t->coef, t->coef + (size_t)NCOEF * t->nb);
     std::vector<double> wsrf(t->wl_srf, t->wl_srf + (size_t)t->nsrf * t->nb), psrf(t->p_srf, t->p_srf + (size_t)t->nsrf * t->nb);
     double *d_w = nullptr, *d_p = nullptr;

@@ -223,6 +223,39 @@ __global__ __launch_bounds__(TILE) void k_bands(const T* __restrict__ tab, const
   }
 }
 
+// Pruned mode (spart_materialize.prune_unused_bands = 1, NOT "full spectra"): only the <= 2 nb bands the sensor
+// columns depend on are evaluated -- one lane per (sample, slot); the band's table row is gathered and the
+// sample's constants are read per lane (neighbouring lanes share them through L1).  Identical arithmetic
+// (leaf_band / soil_band / canopy_band), identical G rows, ~150x less work than k_bands.
+template <typename T>
+__global__ __launch_bounds__(256) void k_bands_pruned(const T* __restrict__ tab, const T* __restrict__ cst,
+                                                      const int* __restrict__ slot_band, int nslot,
+                                                      T* __restrict__ G, int64_t B) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * nslot) return;
+  const int64_t s = i / nslot;
+  const int q = (int)(i - s * nslot);
+  const int band = slot_band[q];
+  const bool thermal = band == NWL;
+  const BandTab<T> tb = load_tab(tab, band < NWL ? band : NWL - 1);
+  const T* __restrict__ c = cst + s * NCONST;
+  T refl, tran, absb, K;
+  leaf_band<T>(tb, c[C_CAB], c[C_CCA], c[C_CDM], c[C_CW], c[C_CS], c[C_CANT], c[C_CBC], c[C_PROT], c[C_NM1], refl,
+               tran, absb, K);
+  T rdry = soil_dry<T>(tb, c[C_F1], c[C_F2], c[C_F3]);
+  T fm[7] = {c[C_FM0], c[C_FM1], c[C_FM2], c[C_FM3], c[C_FM4], c[C_FM5], c[C_FM6]};
+  T rwet;
+  soil_band<T>(tb, rdry, c[C_WET], fm, c[C_FMSUM], c[C_FILM2], rwet);
+  T rho = thermal ? c[C_RHO_TH] : refl;
+  T tau = thermal ? c[C_TAU_TH] : tran;
+  T ab = thermal ? (T(1) - c[C_RHO_TH] - c[C_TAU_TH]) : absb;
+  const CanopyPar<T> cp = load_canopy(c);
+  T rso, rdo, rsd, rdd;
+  canopy_band<T>(cp, rho, tau, ab, rwet, rso, rdo, rsd, rdd);
+  T* g = G + i * 4;
+  g[0] = rso; g[1] = rdo; g[2] = rsd; g[3] = rdd;
+}
+
 // batch-mean canopy spectra from the per-chunk band sums: out (4, 2162) = mean over samples of rso, rdo, rsd, rdd
 template <typename T>
 __global__ __launch_bounds__(256) void k_bandmean(const T* __restrict__ bandsum, int64_t nchunk, int64_t B,
