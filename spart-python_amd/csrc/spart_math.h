@@ -514,15 +514,19 @@ SPART_HD double lidf_dcum_newton(double a, double b, double theta_deg) {
   if (!(::fabs(a) + ::fabs(b) < 0.95)) return lidf_dcum(a, b, theta_deg);
   const double rd = PI / 180.0;
   const double theta2 = 2.0 * rd * theta_deg;
-  double x = theta2;
+  // start from one fixed-point step x1 = theta2 + y(theta2) (error <~ 0.05), then Newton: 0.05 -> 1e-3 -> 1e-6 ->
+  // 1e-12; the loop leaves as soon as a step is below 1e-9 (the next iterate is then exact to ~1e-17, far inside
+  // the ~1e-8 of the reference's own stopping rule)
+  double sn, cs;
+  ::sincos(theta2, &sn, &cs);
+  double x = theta2 + sn * (a + b * cs);
   for (int it = 0; it < 12; ++it) {
-    double sn, cs;
     ::sincos(x, &sn, &cs);
     double f = x - theta2 - sn * (a + b * cs);
     double fp = 1.0 - a * cs - b * (2.0 * cs * cs - 1.0);
     double d = f / fp;
     x -= d;
-    if (::fabs(d) < 1e-13) break;
+    if (::fabs(d) < 1e-9) break;
   }
   return (2.0 * (x - theta2) + theta2) / PI;
 }
