@@ -100,3 +100,25 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".h", ".hip")):
                 src = open(os.path.join(d, f)).read()
                 assert "spart_oracle" not in src and "hostmath" not in src.replace("tests/hostmath", ""), f
+
+
+def test_batch_result_long_dataframe():
+    """BatchResult.to_dataframe: the batched counterpart of the reference's per-run table (SPART.py:256-260)."""
+    import SPART
+    B, nb = 3, 4
+    data = {k: np.arange(B * nb, dtype=np.float64).reshape(B, nb) + i for i, k in enumerate(("R_TOC", "R_TOA", "L_TOA"))}
+    data["rsoil"] = np.ones((B, nb))
+    res = SPART.BatchResult(data, np.array([443, 490, 560, 665]), ["B1", "B2", "B3", "B4"])
+    df = res.to_dataframe()
+    assert list(df.columns) == ["Band", "L_TOA", "R_TOA", "R_TOC", "rsoil"]
+    assert df.index.names == ["sample", "wavelength"] and len(df) == B * nb
+    assert df.loc[(2, 560), "R_TOC"] == data["R_TOC"][2, 2] and df.loc[(1, 443), "Band"] == "B1"
+
+
+def test_engine_input_validation_messages():
+    """Host-side checks that run before any GPU work."""
+    import SPART
+    with pytest.raises(NotImplementedError):
+        SPART.SoilParametersFromFile("some_file.txt", 20, 25, 0.015)      # JPL text parsing is out of scope
+    s = SPART.SoilParametersFromFile(np.zeros((2001, 1)), 20, 25, 0.015)
+    assert s.rdry_set is True and s.columns()[:3] == [None, None, None]
