@@ -13,3 +13,7 @@ for chunk in (1 << 18, 1 << 20):
     spart_amd.generate_lut(P, "Sentinel2A-MSI", chunk=chunk)
     dt = time.perf_counter() - t0
     print(f"B={B} chunk={chunk}: {B/dt:.3e} spectra/s end to end (host table in, host columns out), {dt*1e3:.1f} ms")
+    t0 = time.perf_counter()
+    spart_amd.generate_lut(P, "Sentinel2A-MSI", chunk=chunk, prune=True)
+    dt = time.perf_counter() - t0
+    print(f"B={B} chunk={chunk} prune=True: {B/dt:.3e} spectra/s end to end, {dt*1e3:.1f} ms")
