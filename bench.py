@@ -32,10 +32,10 @@ def algorithmic_bytes(nb, dtype):
 
 def measured_traffic(kernel):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r1_e_traffic.json; FETCH_SIZE and WRITE_SIZE need separate passes, so this cannot be
+    (profiles/r1_f_traffic.json; FETCH_SIZE and WRITE_SIZE need separate passes, so this cannot be
     collected live).  None when the profile does not cover this kernel / batch."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r1_e_traffic.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", "r1_f_traffic.json")))
         for k, v in d.items():
             if k.replace(" ", "") == "spart::" + kernel.replace(" ", ""):
                 return v["hbm_bytes_per_launch"]
