@@ -39,7 +39,7 @@ def build(force=False, fast_math=None, verbose=True, out=None, extra=()):
     if out is not None:
         cmd = [hipcc(), *FLAGS, "-o", out, SRC, "-DSPART_FAST_MATH=1", *extra]
         if verbose:
-            print("[spart_amd] " + " ".join(cmd), flush=True)
+            print("[spart_amd] " + " ".join(cmd), file=sys.stderr, flush=True)
         subprocess.check_call(cmd)
         return out
     if fast_math is None:
@@ -50,7 +50,7 @@ def build(force=False, fast_math=None, verbose=True, out=None, extra=()):
     if fast_math:
         cmd.insert(1, "-DSPART_FAST_MATH=1")
     if verbose:
-        print("[spart_amd] " + " ".join(cmd), flush=True)
+        print("[spart_amd] " + " ".join(cmd), file=sys.stderr, flush=True)
     subprocess.check_call(cmd)
     return OUT
 
