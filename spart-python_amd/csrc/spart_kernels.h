@@ -102,7 +102,7 @@ template <typename T> __device__ __forceinline__ BandTab<T> load_tab(const T* __
 template <typename T> __device__ __forceinline__ CanopyPar<T> load_canopy(const T* __restrict__ c) {
   CanopyPar<T> cp;
   cp.sob = c[C_SOB]; cp.sof = c[C_SOF];
-  cp.bf = c[C_BF]; cp.ks = c[C_KS]; cp.ko = c[C_KO]; cp.lai = c[C_LAI];
+  cp.hbf = c[C_HBF]; cp.ks = c[C_KS]; cp.ko = c[C_KO]; cp.lai = c[C_LAI]; cp.lai2 = c[C_LAI2];
   cp.tss = c[C_TSS]; cp.too = c[C_TOO]; cp.Z = c[C_Z]; cp.hot = c[C_HOT]; cp.pso2w = c[C_PSO2W];
   return cp;
 }
@@ -162,10 +162,13 @@ __global__ __launch_bounds__(TILE) void k_bands(const T* __restrict__ tab, const
     T rdry = (MAT && mat.rdry_in) ? mat.rdry_in[s * NWL + ti] : soil_dry<T>(tb, c[C_F1], c[C_F2], c[C_F3]);
     T fm[7] = {c[C_FM0], c[C_FM1], c[C_FM2], c[C_FM3], c[C_FM4], c[C_FM5], c[C_FM6]};
     T rwet;
-    soil_band<T>(tb, rdry, c[C_WET], fm, c[C_FMSUM], c[C_FILM2], rwet);
-    T rho = thermal ? c[C_RHO_TH] : refl;              // SPART.py:463-466
-    T tau = thermal ? c[C_TAU_TH] : tran;
-    T ab = thermal ? (T(1) - c[C_RHO_TH] - c[C_TAU_TH]) : absb;
+    soil_band<T>(tb, rdry, c[C_WET], fm, c[C_FMSUM], c[C_FILM2L], rwet);
+    T rho = refl, tau = tran, ab = absb;
+    if (tile == NTILE - 1) {                           // block-uniform: only the last tile holds the thermal evaluation
+      rho = thermal ? c[C_RHO_TH] : refl;              // SPART.py:463-466
+      tau = thermal ? c[C_TAU_TH] : tran;
+      ab = thermal ? (T(1) - c[C_RHO_TH] - c[C_TAU_TH]) : absb;
+    }
     const CanopyPar<T> cp = load_canopy(c);
     T rso, rdo, rsd, rdd;
     canopy_band<T>(cp, rho, tau, ab, rwet, rso, rdo, rsd, rdd);
@@ -245,7 +248,7 @@ __global__ __launch_bounds__(256) void k_bands_pruned(const T* __restrict__ tab,
   T rdry = soil_dry<T>(tb, c[C_F1], c[C_F2], c[C_F3]);
   T fm[7] = {c[C_FM0], c[C_FM1], c[C_FM2], c[C_FM3], c[C_FM4], c[C_FM5], c[C_FM6]};
   T rwet;
-  soil_band<T>(tb, rdry, c[C_WET], fm, c[C_FMSUM], c[C_FILM2], rwet);
+  soil_band<T>(tb, rdry, c[C_WET], fm, c[C_FMSUM], c[C_FILM2L], rwet);
   T rho = thermal ? c[C_RHO_TH] : refl;
   T tau = thermal ? c[C_TAU_TH] : tran;
   T ab = thermal ? (T(1) - c[C_RHO_TH] - c[C_TAU_TH]) : absb;
@@ -317,7 +320,7 @@ __global__ __launch_bounds__(TILE) void k_bsm(const T* __restrict__ tab, const T
     T rdry = rdry_in ? (active ? rdry_in[s * NWL + band] : T(0)) : soil_dry<T>(tb, c[C_F1], c[C_F2], c[C_F3]);
     T fm[7] = {c[C_FM0], c[C_FM1], c[C_FM2], c[C_FM3], c[C_FM4], c[C_FM5], c[C_FM6]};
     T rwet;
-    soil_band<T>(tb, rdry, c[C_WET], fm, c[C_FMSUM], c[C_FILM2], rwet);
+    soil_band<T>(tb, rdry, c[C_WET], fm, c[C_FMSUM], c[C_FILM2L], rwet);
     if (active) {
       const int64_t o = s * NWL + band;
       if (o_refl) o_refl[o] = rwet;

@@ -33,6 +33,19 @@
 #define SPART_NO_CONTRACT
 #endif
 
+// True when the condition holds in ANY lane of the wave (device) / for this value (host): lets a rare per-lane
+// branch be skipped with a scalar branch instead of being issued under an all-zero exec mask (short masked
+// blocks get no s_cbranch_execz from the compiler and cost their full issue slots)
+// SPART_KEEP_BRANCH(x), placed inside such a block, stops the compiler from if-converting it back into
+// unconditional arithmetic + select (an empty, non-speculatable asm that "touches" x).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SPART_WAVE_ANY(c) (__builtin_amdgcn_ballot_w64(c) != 0)
+#define SPART_KEEP_BRANCH(x) asm volatile("" : "+v"(x))
+#else
+#define SPART_WAVE_ANY(c) (c)
+#define SPART_KEEP_BRANCH(x) ((void)0)
+#endif
+
 #include "spart_e3_coeffs.h"
 
 namespace spart {
@@ -58,6 +71,13 @@ template <> struct Mx<float> {
     return __expf(x);
 #else
     return ::expf(x);
+#endif
+  }
+  static SPART_HD float exp2(float x) {   // arguments here are <= 0 and far from the denormal range of the result
+#if defined(__HIP_DEVICE_COMPILE__) && defined(SPART_FAST_MATH)
+    return __builtin_amdgcn_exp2f(x);     // v_exp_f32
+#else
+    return ::exp2f(x);
 #endif
   }
   static SPART_HD float log(float x) {
@@ -102,6 +122,21 @@ template <> struct Mx<float> {
     return -::expm1f(-z);
 #endif
   }
+  // the same with ez = e^-z already at hand: the Taylor side is only issued when some lane needs it
+  static SPART_HD float one_minus_exp_neg(float z, float ez) {
+#if defined(SPART_FAST_MATH)
+    float v = 1.0f - ez;
+    if (SPART_WAVE_ANY(z < 0.25f)) {
+      float p = z * (1.0f + z * (-0.5f + z * (0.166666667f + z * (-0.0416666667f + z * (8.33333333e-3f +
+                z * (-1.38888889e-3f + z * 1.98412698e-4f))))));
+      v = (z < 0.25f) ? p : v;
+    }
+    return v;
+#else
+    (void)ez;
+    return -::expm1f(-z);
+#endif
+  }
   static SPART_HD float expm1(float x) { return ::expm1f(x); }
   static SPART_HD float fabs(float x) { return ::fabsf(x); }
   static SPART_HD float fmax(float a, float b) { return ::fmaxf(a, b); }
@@ -111,6 +146,7 @@ template <> struct Mx<float> {
 
 template <> struct Mx<double> {
   static SPART_HD double exp(double x) { return ::exp(x); }
+  static SPART_HD double exp2(double x) { return ::exp2(x); }
   static SPART_HD double log(double x) { return ::log(x); }
   static SPART_HD double sqrt(double x) { return ::sqrt(x); }
   // reciprocal: v_rcp_f64 refined by two Newton steps (~1 ulp for normal arguments, 5 instructions) instead of
@@ -164,6 +200,14 @@ template <> struct Mx<double> {
     return -::expm1(-z);
 #endif
   }
+  static SPART_HD double one_minus_exp_neg(double z, double ez) {
+#if defined(SPART_FAST_MATH)
+    return (z < 0.02) ? one_minus_exp_neg(z) : 1.0 - ez;
+#else
+    (void)ez;
+    return -::expm1(-z);
+#endif
+  }
   static SPART_HD double expm1(double x) { return ::expm1(x); }
   static SPART_HD double fabs(double x) { return ::fabs(x); }
   static SPART_HD double fmax(double a, double b) { return ::fmax(a, b); }
@@ -183,41 +227,39 @@ template <typename T> SPART_HD T phi_fn(T d) {
 
 // SAIL J-functions (sailh.py:154-183) for x = -1 / x = 0:
 //   J1 = (e^-mL - e^-kL)/(k - m) = L e^-kL phi((m-k)L),   J2 = (1 - e^-kL e^-mL)/(k + m) = L phi((k+m)L)
-// float shares e1 = exp(-m L) between the four of them and switches to the Taylor polynomial of phi
-// for |d| < 0.06 (next term d^5/720 = 1e-9), so no difference of nearly equal exponentials is formed;
-// double goes through expm1.
+// e1 = exp(-m L) is shared between the four of them; below |d| < THRESH the Taylor polynomial of phi replaces
+// the difference of nearly equal exponentials (float: 0.06, next term d^5/720 = 1e-9).
 template <typename T> struct SailJ;
 template <> struct SailJ<float> {
+  static constexpr float THRESH = 0.06f;
   static SPART_HD float poly(float d) {
     return 1.0f + d * (-0.5f + d * (0.166666667f + d * (-0.0416666667f + d * 8.33333333e-3f)));
-  }
-  static SPART_HD bool small(float d) { return ::fabsf(d) < 0.06f; }
-  static SPART_HD float j1(float L, float tk, float e1, float d, float id) {  // d = (m - k) L, tk = e^-kL, id = 1/d
-    if (small(d)) return L * tk * poly(d);
-    return L * (tk - e1) * id;
-  }
-  static SPART_HD float j2(float L, float tk, float e1, float kpm, float ikpm) {  // kpm = k + m > 0, ikpm = 1/kpm
-    float d = kpm * L;
-    float v = (1.0f - tk * e1) * ikpm;
-    return (d < 0.06f) ? L * poly(d) : v;
   }
 };
 template <> struct SailJ<double> {
   // |d| < 2e-3: Taylor polynomial of phi to d^5 (next term d^6/5040 < 2e-20); outside, the difference of
   // exponentials loses at most 1e-16/2e-3 relative
+  static constexpr double THRESH = 2e-3;
   static SPART_HD double poly(double d) {
     return 1.0 + d * (-0.5 + d * (1.0 / 6.0 + d * (-1.0 / 24.0 + d * (1.0 / 120.0 - d * (1.0 / 720.0)))));
   }
-  static SPART_HD bool small(double d) { return ::fabs(d) < 2e-3; }
-  static SPART_HD double j1(double L, double tk, double e1, double d, double id) {
-    if (small(d)) return L * tk * poly(d);
-    return L * (tk - e1) * id;
-  }
-  static SPART_HD double j2(double L, double tk, double e1, double kpm, double ikpm) {
-    double d = kpm * L;
-    return (d < 2e-3) ? L * poly(d) : (1.0 - tk * e1) * ikpm;
-  }
 };
+// J1 = L (tk - e1)/d with tk = e^-kL, e1 = e^-mL, d = (m - k) L, id = 1/d (unused on the Taylor side)
+template <typename T> SPART_HD T sail_j1_d(T L, T tk, T e1, T d, T id) {
+  if (Mx<T>::fabs(d) < SailJ<T>::THRESH) return L * tk * SailJ<T>::poly(d);
+  return L * (tk - e1) * id;
+}
+// J2 = (1 - tk e1)/(k + m), kpm = k + m > 0, ikpm = 1/kpm; (k + m) L < THRESH selects L phi((k + m) L) -- rare, and
+// the Taylor side is only issued when some lane of the wave needs it
+template <typename T> SPART_HD T sail_j2_d(T L, T tk, T e1, T kpm, T ikpm) {
+  T d = kpm * L;
+  T v = (T(1) - tk * e1) * ikpm;
+  if (SPART_WAVE_ANY(d < SailJ<T>::THRESH)) {
+    SPART_KEEP_BRANCH(d);
+    v = (d < SailJ<T>::THRESH) ? L * SailJ<T>::poly(d) : v;
+  }
+  return v;
+}
 
 // ------------------------------------------------------------------------------------------
 // tau(K) = (1-K) exp(-K) + K^2 E1(K) = 2 E3(K)           (prospect_5d.py:183-196)
@@ -252,13 +294,13 @@ template <typename T> SPART_HD void plate_tau(T K, T& tau, T& u) {
   } else {
     // P(t)/Q(t) with t = 1/x, written in x (coefficients reversed) so that a single reciprocal is needed:
     // tau = e^-x * 2 Pr(x) / ((x + 3) Qr(x)),  Pr(x) = x^n P(1/x)
-    T pn = C::p(0), qn = C::q(0);
+    T pn = T(2) * C::p(0), qn = C::q(0);   // (the factor 2 is folded into P's constants: exact)
 #pragma unroll
     for (int i = 1; i <= C::WD; ++i) {
-      pn = pn * x + C::p(i);
+      pn = pn * x + T(2) * C::p(i);
       qn = qn * x + C::q(i);
     }
-    v = Mx<T>::exp(-x) * (T(2) * pn) * Mx<T>::rcp((x + T(3)) * qn);
+    v = Mx<T>::exp(-x) * pn * Mx<T>::rcp((x + T(3)) * qn);
   }
   T w = T(1) - v;
   u = small ? v : w;
@@ -315,7 +357,7 @@ enum ConstIdx {
   // canopy (sailh.py:93-105, 200-203, 216, 219)
   C_SDB, C_SDF, C_DDB, C_DDF, C_DOB, C_DOF, C_SOB, C_SOF, C_BF, C_KS, C_KO, C_LAI,
   C_TSS, C_TOO, C_Z, C_HOT, C_PSO2W,
-  C_FMSUM, C_RSV1, C_RSV2, C_RSV3, C_RSV4, C_RSV5, C_RSV6, C_RSV7,
+  C_FMSUM, C_HBF, C_LAI2, C_FILM2L, C_RSV4, C_RSV5, C_RSV6, C_RSV7,
   NCONST  // 48
 };
 static_assert(NCONST == 48, "constant block is 48 values");
@@ -360,7 +402,7 @@ SPART_HD void leaf_band(const BandTab<T>& tb, T cab, T cca, T cdm, T cw, T cs, T
   T a = T(1) + am1;
   T z = nm1 * Mx<T>::log1p(bm1);  // (N-1) ln b
   T sq = Mx<T>::exp(-z);          // b^-(N-1)
-  T omsq = Mx<T>::one_minus_exp_neg(z);  // 1 - b^-(N-1)
+  T omsq = Mx<T>::one_minus_exp_neg(z, sq);  // 1 - b^-(N-1)
   T omq = omsq * (T(1) + sq);     // 1 - b^-2(N-1)
   T A2 = am1 * (a + T(1));        // a^2 - 1
   // Rsub = a omq / den, Tsub = sq A2 / den, den = A2 + omq (:229-230 divided by b^2(N-1)); combined with the top
@@ -378,9 +420,9 @@ SPART_HD void leaf_band(const BandTab<T>& tb, T cab, T cca, T cdm, T cw, T cs, T
 // ------------------------------------------------------------------------------------------
 // BSM + soilwat, one band                                        (bsm.py:49-52, 99-124)
 template <typename T>
-SPART_HD void soil_band(const BandTab<T>& tb, T rdry, T wet, const T fm[7], T fmsum16, T film2, T& rwet) {
+SPART_HD void soil_band(const BandTab<T>& tb, T rdry, T wet, const T fm[7], T fmsum16, T film2l, T& rwet) {
   T rbac = T(1) - (T(1) - rdry) * (rdry * tb.cbac + T(1) - rdry);  // :110-112
-  T tw1 = Mx<T>::exp(-film2 * tb.kw);                              // :122 with k = 1
+  T tw1 = Mx<T>::exp2(-film2l * tb.kw);                            // :122 with k = 1; film2l = 2 film log2(e)
   // rwet = rdry f0 + sum_k f_k [Rw + (1-Rw)(1-p) x_k/(1 - p x_k)],  x_k = tw1^k rbac   (:123-124)
   // The six reciprocals 1/d_k, d_k = 1 - p x_k, come from ONE reciprocal of their product (prefix products
   // forward, peel-off backward): a v_rcp costs about five plain VALU ops in this instruction mix
@@ -415,22 +457,19 @@ template <typename T> SPART_HD T soil_dry(const BandTab<T>& tb, T f1, T f2, T f3
 // (the six geometric factors sdb..dof of sailh.py:100-105 are (k +- bf)/2, (1 +- bf)/2, (K +- bf)/2; canopy_band
 // works from ks, ko, bf directly -- the prelude still writes them to the constant block for inspection)
 template <typename T> struct CanopyPar {
-  T sob, sof, bf, ks, ko, lai, tss, too, Z, hot, pso2w;
+  T sob, sof, hbf, ks, ko, lai, lai2, tss, too, Z, hot, pso2w;   // hbf = bf/2, lai2 = LAI log2(e)
 };
 
 template <typename T>
 SPART_HD void canopy_band(const CanopyPar<T>& c, T rho, T tau, T absb, T rs, T& rso, T& rdo, T& rsd, T& rdd) {
   // scattering coefficients (:142-148).  With sdb/sdf = (k +- bf)/2, ddb/ddf = (1 +- bf)/2, dob/dof = (K +- bf)/2
   // (:100-105) they are P, k P, K P plus/minus Mn, where P = (rho + tau)/2 and Mn = bf (rho - tau)/2:
+  //   sigb = P + Mn, sigf = P - Mn, sb/sf = k P +- Mn, vb/vf = K P +- Mn
   T P = T(0.5) * (rho + tau);
-  T Mn = (T(0.5) * c.bf) * (rho - tau);
+  T Mn = c.hbf * (rho - tau);
   T sigb = P + Mn;                     // diffuse backscatter
-  T sigf = P - Mn;                     // diffuse forward scatter
-  T kP = c.ks * P, KP = c.ko * P;
-  T sb = kP + Mn, sf = kP - Mn;        // specular back / forward
-  T vb = KP + Mn, vf = KP - Mn;        // directional back / forward
   T w = c.sob * rho + c.sof * tau;     // bidirectional
-  T a = T(1) - sigf;                   // :149
+  T a = T(1) - P + Mn;                 // 1 - sigf  (:149)
   // m^2 = a^2 - sigb^2 = (a - sigb)(a + sigb), a - sigb = 1 - rho - tau, a + sigb = 1 + 2 Mn   (:150)
   T m = Mx<T>::sqrt(absb * (T(1) + T(2) * Mn));
   // three reciprocals from one: 1/(a+m), 1/(ks+m), 1/(ko+m)
@@ -444,26 +483,31 @@ SPART_HD void canopy_band(const CanopyPar<T>& c, T rho, T tau, T absb, T rs, T& 
   T rinf2 = rinf * rinf;
   // 1 - rinf = (a - sigb + m)/(a + m) = (absorptance + m)/(a + m): no cancellation for nearly
   // conservative leaves (rinf -> 1)
-  T omr2 = (absb + m) * iam * (T(1) + rinf);   // 1 - rinf^2
+  T omr = (absb + m) * iam;            // 1 - rinf
+  T opr = T(1) + rinf;
+  T omr2 = omr * opr;                  // 1 - rinf^2
   T L = c.lai;
-  // J1(-1) = (e^-mL - e^-kL)/(k - m) = L e^-kL phi((m-k)L)   (:154-170, 180-183)
-  T e1 = Mx<T>::exp(-m * L);           // :185-189
+  // J1(-1) = (e^-mL - e^-kL)/(k - m), J2(0) = (1 - e^-kL e^-mL)/(k + m)   (:154-183)
+  T e1 = Mx<T>::exp2(-m * c.lai2);     // e^-mL, :185-189
+  const T thr = SailJ<T>::THRESH;
   T d1 = (m - c.ks) * L, d2 = (m - c.ko) * L;
-  T d1s = SailJ<T>::small(d1) ? T(1) : d1, d2s = SailJ<T>::small(d2) ? T(1) : d2;   // (the Taylor branch needs no 1/d)
+  T d1s = (Mx<T>::fabs(d1) < thr) ? T(1) : d1, d2s = (Mx<T>::fabs(d2) < thr) ? T(1) : d2;   // (the Taylor side needs no 1/d)
   T idd = Mx<T>::rcp(d1s * d2s);
-  T J1k = SailJ<T>::j1(L, c.tss, e1, d1, idd * d2s);
-  T J1K = SailJ<T>::j1(L, c.too, e1, d2, idd * d1s);
-  // J2(0) = (1 - e^-kL e^-mL)/(k + m) = L phi((k+m)L)        (:172-177)
-  T J2k = SailJ<T>::j2(L, c.tss, e1, ksm, iks);
-  T J2K = SailJ<T>::j2(L, c.too, e1, kom, iko);
+  T J1k = sail_j1_d<T>(L, c.tss, e1, d1, idd * d2s);
+  T J1K = sail_j1_d<T>(L, c.too, e1, d2, idd * d1s);
+  T J2k = sail_j2_d<T>(L, c.tss, e1, ksm, iks);
+  T J2K = sail_j2_d<T>(L, c.too, e1, kom, iko);
   T ome2 = T(1) - e1 * e1;
   T re = rinf * e1;
   T i1 = Mx<T>::rcp(omr2 * (T(1) + rinf2));  // sic: 1/(1 - rinf2**2) (:189)
   T i2 = (T(1) + rinf2) * i1;                 // 1/(1 - rinf2)  (:214)
-  T s1 = sf + rinf * sb;               // :191-198
-  T s2 = sf * rinf + sb;
-  T v1 = vf + rinf * vb;
-  T v2 = vf * rinf + vb;
+  // s1 = sf + rinf sb, s2 = sf rinf + sb, v1 = vf + rinf vb, v2 = vf rinf + vb (:191-198) in terms of
+  // U = P (1 + rinf), V = Mn (1 - rinf):
+  T U = P * opr, V = Mn * omr;
+  T s1 = c.ks * U - V;
+  T s2 = c.ks * U + V;
+  T v1 = c.ko * U - V;
+  T v2 = c.ko * U + V;
   T Pss = s1 * J1k, Qss = s2 * J2k, Poo = v1 * J1K, Qoo = v2 * J2K;
   T tau_dd = omr2 * e1 * i1;             // :205-210
   T rho_dd = rinf * ome2 * i1;
@@ -475,12 +519,13 @@ SPART_HD void canopy_band(const CanopyPar<T>& c, T rho, T tau, T absb, T rs, T& 
   T T2 = -(Qoo * rho_sd + Poo * tau_sd) * rinf;                                      // :213
   T rho_sod = (T1 + T2) * i2;                                                        // :214
   T rho_so = rho_sod + w * c.hot;                                 // :216-217
-  T idn = Mx<T>::rcp(T(1) - rs * rho_dd);                         // :222
-  rso = rho_so + rs * c.pso2w +
-        ((tau_sd + c.tss * rs * rho_dd) * c.too + (tau_sd + c.tss) * tau_do) * rs * idn;  // :224-230
-  rdo = rho_do + (c.too + tau_do) * rs * tau_dd * idn;            // :231
-  rsd = rho_sd + (c.tss + tau_sd) * rs * tau_dd * idn;            // :232
-  rdd = rho_dd + tau_dd * rs * tau_dd * idn;                      // :233
+  T g = rs * Mx<T>::rcp(T(1) - rs * rho_dd);                      // rs / (1 - rs rho_dd)   (:222)
+  T h = g * tau_dd;
+  T tst = c.tss + tau_sd;
+  rso = rho_so + rs * c.pso2w + ((tau_sd + c.tss * rs * rho_dd) * c.too + tst * tau_do) * g;  // :224-230
+  rdo = rho_do + (c.too + tau_do) * h;                            // :231
+  rsd = rho_sd + tst * h;                                         // :232
+  rdd = rho_dd + tau_dd * h;                                      // :233
 }
 
 // ------------------------------------------------------------------------------------------
@@ -711,6 +756,7 @@ SPART_HD void sample_prelude(const double* p /*[27]*/, double rho_th, double tau
     cst[C_FMSUM] = T(fsum);
   }
   cst[C_FILM2] = T(2.0 * film);
+  cst[C_FILM2L] = T(2.0 * film * 1.4426950408889634);
   }
   double tts = p[19], tto = p[20], rel = p[21];
   if (mask & PRE_CANOPY) {
@@ -750,9 +796,11 @@ SPART_HD void sample_prelude(const double* p /*[27]*/, double rho_th, double tau
   cst[C_SOB] = T(sob);
   cst[C_SOF] = T(sof);
   cst[C_BF] = T(bf);
+  cst[C_HBF] = T(0.5 * bf);
   cst[C_KS] = T(ks);
   cst[C_KO] = T(ko);
   cst[C_LAI] = T(LAI);
+  cst[C_LAI2] = T(LAI * 1.4426950408889634);
   double tss = ::exp(-ks * LAI), too = ::exp(-ko * LAI);  // :200-201
   cst[C_TSS] = T(tss);
   cst[C_TOO] = T(too);

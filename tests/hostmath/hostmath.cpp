@@ -29,7 +29,7 @@ static void bands_impl(int64_t B, const double* tab, const double* P, double* ou
     std::memcpy(atm_out + s * NATM, a, sizeof(a));
     std::memcpy(lidf_out + s * NLINCL, li, sizeof(li));
     CanopyPar<T> cp;
-    cp.sob = c[C_SOB]; cp.sof = c[C_SOF]; cp.bf = c[C_BF]; cp.ks = c[C_KS]; cp.ko = c[C_KO]; cp.lai = c[C_LAI];
+    cp.sob = c[C_SOB]; cp.sof = c[C_SOF]; cp.hbf = c[C_HBF]; cp.ks = c[C_KS]; cp.ko = c[C_KO]; cp.lai = c[C_LAI]; cp.lai2 = c[C_LAI2];
     cp.tss = c[C_TSS]; cp.too = c[C_TOO]; cp.Z = c[C_Z]; cp.hot = c[C_HOT]; cp.pso2w = c[C_PSO2W];
     for (int band = 0; band < NEVAL; ++band) {
       bool thermal = band == NWL;
@@ -40,7 +40,7 @@ static void bands_impl(int64_t B, const double* tab, const double* P, double* ou
       T rdry = soil_dry<T>(tb, c[C_F1], c[C_F2], c[C_F3]);
       T fm[7] = {c[C_FM0], c[C_FM1], c[C_FM2], c[C_FM3], c[C_FM4], c[C_FM5], c[C_FM6]};
       T rwet;
-      soil_band<T>(tb, rdry, c[C_WET], fm, c[C_FMSUM], c[C_FILM2], rwet);
+      soil_band<T>(tb, rdry, c[C_WET], fm, c[C_FMSUM], c[C_FILM2L], rwet);
       T rho = thermal ? c[C_RHO_TH] : refl, tau = thermal ? c[C_TAU_TH] : tran;
       T ab = thermal ? (T(1) - c[C_RHO_TH] - c[C_TAU_TH]) : absb;
       T rso, rdo, rsd, rdd;
