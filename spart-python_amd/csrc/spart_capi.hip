@@ -116,6 +116,8 @@ struct Workspace {
 // min(32, B/256) samples per workgroup so that the 17 table loads per lane are amortised while ~2000
 // workgroups remain.
 int pick_chunk(int64_t B) {
+  static const int forced = [] { const char* e = std::getenv("SPART_CHUNK"); return e ? std::atoi(e) : 0; }();   // tuning knob
+  if (forced > 0) return forced;
   int64_t c = (B + 2047) / 2048;
   int64_t small = (B + 255) / 256;
   if (small > 32) small = 32;
