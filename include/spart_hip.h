@@ -15,7 +15,8 @@
  *     data_ptr()); the library allocates only its context and never frees caller memory;
  *   - per-sample inputs are structure-of-arrays, float64, length B (sample-level geometry is
  *     always computed in float64);
- *   - spectra and result columns are row-major (B, nbands), band-contiguous, in `dtype`;
+ *   - spectra and result columns are row-major (B, nbands), band-contiguous, in `dtype`; the row pitch of the
+ *     2162- / 2001-wide spectrum arrays is the row width unless spart_ctx_set_row_pitch says otherwise;
  *   - `stream` is a hipStream_t (NULL = default stream); calls are asynchronous on it;
  *   - return value 0 = ok, <0 = error (spart_last_error gives the text).  Numerical trouble
  *     propagates as NaN/inf exactly like the reference (no clamping).
@@ -93,6 +94,14 @@ const char *spart_last_error(const spart_ctx *ctx); /* ctx may be NULL: last cre
 
 int spart_ctx_nb(const spart_ctx *ctx);                    /* sensor bands of the context */
 int spart_ctx_econv(const spart_ctx *ctx, double *host_out); /* (nb,) SRF-convolved ET irradiance (SPART.py:389-394), copied to HOST */
+
+/* Row pitch, in elements, of EVERY (B,2162) and (B,2001) spectrum array this context reads or writes (the outputs /
+ * inputs of spart_prospect_batch, spart_bsm_batch, spart_sailh_batch and the spart_materialize members of
+ * spart_run_batch; (B,nb) columns and band_mean stay dense).  Default = dense (2162 / 2001); 0 restores it.
+ * A 2162-float row is 8648 B, so dense rows start off the 128 B line grid and the 1 KB row segments a workgroup
+ * stores straddle lines: on MI355X the materialised store stream then reaches 3.3 TB/s, with rows padded to a
+ * multiple of 64 elements (2176 / 2048) 5.9 TB/s (tools/ubench/write_pattern.hip).  No reference counterpart. */
+int spart_ctx_set_row_pitch(spart_ctx *ctx, int64_t pitch_full, int64_t pitch_optical);
 
 /* Bytes of scratch the batched entry points need for B samples (prelude constants + the
  * canopy values at the sensor bands).  The same buffer may be reused by successive calls

@@ -23,6 +23,7 @@ struct spart_ctx {
   double* tabD = nullptr;   // (NTAB, NWL)
   double* Ea = nullptr;     // (NWL)
   int nb = 0, nslot = 0;
+  int pf = NWLS, po = NWL;  // row pitch (elements) of the 2162- / 2001-wide spectrum arrays (spart_ctx_set_row_pitch)
   int* need_slot = nullptr;  // (2048) eval index -> slot or -1
   int* slot_band = nullptr;  // (nslot) slot -> eval index (pruned mode)
   int* slot0 = nullptr;      // (nb)
@@ -178,7 +179,7 @@ static int prospect_impl(spart_ctx* ctx, int64_t B, const double* const leaf[9],
   int64_t nchunk = (B + chunk - 1) / chunk;
   const T* tab = sizeof(T) == 4 ? (const T*)ctx->tabF : (const T*)ctx->tabD;
   hipLaunchKernelGGL((k_prospect<T>), dim3(xcd_grid(nchunk)), dim3(TILE), 0, st, tab, (const T*)cst, B, chunk,
-                     (T*)refl, (T*)tran, (T*)kchl);
+                     ctx->po, (T*)refl, (T*)tran, (T*)kchl);
   HIP_TRY(ctx, hipGetLastError());
   return SPART_OK;
 }
@@ -196,7 +197,7 @@ static int bsm_impl(spart_ctx* ctx, int64_t B, const double* const soil[6], cons
   int64_t nchunk = (B + chunk - 1) / chunk;
   const T* tab = sizeof(T) == 4 ? (const T*)ctx->tabF : (const T*)ctx->tabD;
   hipLaunchKernelGGL((k_bsm<T>), dim3(xcd_grid(nchunk)), dim3(TILE), 0, st, tab, (const T*)cst, B, chunk,
-                     (const T*)rdry_in, (T*)refl, (T*)dry);
+                     ctx->po, (const T*)rdry_in, (T*)refl, (T*)dry);
   HIP_TRY(ctx, hipGetLastError());
   return SPART_OK;
 }
@@ -215,7 +216,7 @@ static int sailh_impl(spart_ctx* ctx, int64_t B, const void* rho, const void* ta
   int chunk = pick_chunk(B);
   int64_t nchunk = (B + chunk - 1) / chunk;
   hipLaunchKernelGGL((k_sailh<T>), dim3((unsigned)(nchunk * NTILE_FULL)), dim3(TILE), 0, st, (const T*)cst, B, chunk,
-                     (const T*)rho, (const T*)tau, (const T*)rs, (T*)out4[0], (T*)out4[1], (T*)out4[2], (T*)out4[3]);
+                     ctx->pf, (const T*)rho, (const T*)tau, (const T*)rs, (T*)out4[0], (T*)out4[1], (T*)out4[2], (T*)out4[3]);
   HIP_TRY(ctx, hipGetLastError());
   return SPART_OK;
 }
@@ -244,6 +245,7 @@ static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_
   const T* tab = sizeof(T) == 4 ? (const T*)ctx->tabF : (const T*)ctx->tabD;
   MatPtrs<T> mp;
   std::memset(&mp, 0, sizeof(mp));
+  mp.pf = ctx->pf; mp.po = ctx->po;
   bool mat = false;
   if (opt) {
     mp.leaf_refl = (T*)opt->leaf_refl; mp.leaf_tran = (T*)opt->leaf_tran; mp.leaf_kchl = (T*)opt->leaf_kchl;
@@ -256,15 +258,19 @@ static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_
   }
   dim3 grid(xcd_grid(nchunk));
   T* bsum = (T*)(wsp + ws.bs_off);
+  if (mat && (int64_t)chunk * (int64_t)ctx->pf * (int64_t)sizeof(T) > (int64_t)3900000000LL)
+    return fail(ctx, SPART_ERR_INVALID, "batch too large for materialised spectra in one call (chunk %d rows x pitch %d)", chunk, ctx->pf);
   const bool full = !(opt && opt->prune_unused_bands);
   const bool prof = ctx->profile && ctx->ev_used + 2 <= ctx->ev.size();
   if (prof) HIP_TRY(ctx, hipEventRecord(ctx->ev[ctx->ev_used], st));
 #define SPART_LAUNCH_BANDS(M, F)                                                                                 \
   hipLaunchKernelGGL((k_bands<T, M, F>), grid, dim3(TILE), 0, st, tab, (const T*)cst, (const int*)ctx->need_slot, \
                      ctx->nslot, G, B, chunk, mp, bsum)
-  if (mat && full) SPART_LAUNCH_BANDS(true, true);
-  else if (mat) SPART_LAUNCH_BANDS(true, false);
-  else if (full) SPART_LAUNCH_BANDS(false, true);
+  if (mat && mp.rdry_in && full) SPART_LAUNCH_BANDS(2, true);
+  else if (mat && mp.rdry_in) SPART_LAUNCH_BANDS(2, false);
+  else if (mat && full) SPART_LAUNCH_BANDS(1, true);
+  else if (mat) SPART_LAUNCH_BANDS(1, false);
+  else if (full) SPART_LAUNCH_BANDS(0, true);
   else {   // columns only, pruning allowed: evaluate just the sensor's bands
     int64_t n = B * ctx->nslot;
     hipLaunchKernelGGL((k_bands_pruned<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, tab, (const T*)cst,
@@ -339,6 +345,17 @@ extern "C" {
 const char* spart_last_error(const spart_ctx* ctx) { return ctx ? ctx->err : g_err; }
 
 int spart_ctx_nb(const spart_ctx* ctx) { return ctx ? ctx->nb : 0; }
+
+int spart_ctx_set_row_pitch(spart_ctx* ctx, int64_t pitch_full, int64_t pitch_optical) {
+  if (!ctx) return fail(ctx, SPART_ERR_INVALID, "spart_ctx_set_row_pitch: null context");
+  if (pitch_full == 0) pitch_full = NWLS;
+  if (pitch_optical == 0) pitch_optical = NWL;
+  if (pitch_full < NWLS || pitch_optical < NWL || pitch_full > (1 << 20) || pitch_optical > (1 << 20))
+    return fail(ctx, SPART_ERR_INVALID, "row pitch must be >= the row width (%d / %d elements)", NWLS, NWL);
+  ctx->pf = (int)pitch_full;
+  ctx->po = (int)pitch_optical;
+  return SPART_OK;
+}
 
 int spart_ctx_econv(const spart_ctx* ctx, double* host_out) {
   if (!ctx || !host_out) return fail(ctx, SPART_ERR_INVALID, "spart_ctx_econv: null argument");

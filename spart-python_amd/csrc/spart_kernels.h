@@ -107,10 +107,19 @@ template <typename T> __device__ __forceinline__ CanopyPar<T> load_canopy(const 
   return cp;
 }
 
+// Store v at (row + byte_off) where `row` is wave-uniform and loop-invariant: SGPR base + 32-bit VGPR byte offset,
+// the "saddr" form of global_store.  Keeping the per-array bases in SGPRs (instead of one 64-bit per-lane pointer
+// per output array, 22 VGPRs for 11 arrays) is what lets the materialising kernel run at the occupancy of the
+// columns-only one.
+template <typename T> __device__ __forceinline__ void store_row(T* row, unsigned byte_off, T v) {
+  *reinterpret_cast<T*>(reinterpret_cast<char*>(row) + byte_off) = v;
+}
+
 template <typename T> struct MatPtrs {
   T *leaf_refl, *leaf_tran, *leaf_kchl, *soil_refl, *soil_dry, *rso, *rdo, *rsd, *rdd;
   T* gsoil;         // (B, nslot) wet soil at the sensor-band slots (debug column rsoil)
   const T* rdry_in; // optional (B, 2001) user dry-soil spectra (SoilParametersFromFile, bsm.py:42-43)
+  int pf, po;       // row pitch (elements) of the 2162-wide / 2001-wide spectrum arrays (spart_ctx_set_row_pitch)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -124,7 +133,11 @@ template <typename T> struct MatPtrs {
 // Without that the compiler legally sinks most of the soil / canopy arithmetic into the
 // `slot >= 0` store and skips it for the waves that hold no sensor band; that behaviour is the explicit
 // opt-in FULL = false ("prune_unused_bands").
-template <typename T, bool MAT, bool FULL>
+// MAT: 0 = sensor columns only; 1 = also store the requested full spectra; 2 = 1 + per-sample dry-soil spectra are
+// READ (rdry_in).  The read is its own variant because a global load inside the sample loop makes the compiler wait
+// for vmcnt(0) -- i.e. for every outstanding store of the previous sample -- once per sample, which serialises the
+// store stream with the arithmetic (materialised mode 3.4 -> 5.x TB/s without it).
+template <typename T, int MAT, bool FULL>
 __global__ __launch_bounds__(TILE) void k_bands(const T* __restrict__ tab, const T* __restrict__ cst,
                                                 const int* __restrict__ need_slot, int nslot, T* __restrict__ G,
                                                 int64_t B, int chunk, MatPtrs<T> mat, T* __restrict__ bandsum) {
@@ -141,6 +154,21 @@ __global__ __launch_bounds__(TILE) void k_bands(const T* __restrict__ tab, const
   const int64_t s0 = ck * chunk;
   const int64_t s1 = (s0 + chunk < B) ? s0 + chunk : B;
   T sum_so = T(0), sum_do = T(0), sum_sd = T(0), sum_dd = T(0);
+  // materialised rows: array bases of this chunk's first sample stay in SGPRs for the whole chunk; the lane carries
+  // (band + row * pitch) as a 32-bit byte offset that advances by one pitch per sample (host: chunk * pitch < 2 GB)
+  unsigned off_f = (unsigned)band * (unsigned)sizeof(T), off_o = off_f;
+  if (MAT) {
+    const int64_t b0f = s0 * mat.pf, b0o = s0 * mat.po;
+    if (mat.leaf_refl) mat.leaf_refl += b0f;
+    if (mat.leaf_tran) mat.leaf_tran += b0f;
+    if (mat.soil_refl) mat.soil_refl += b0f;
+    if (mat.rso) mat.rso += b0f;
+    if (mat.rdo) mat.rdo += b0f;
+    if (mat.rsd) mat.rsd += b0f;
+    if (mat.rdd) mat.rdd += b0f;
+    if (mat.leaf_kchl) mat.leaf_kchl += b0o;
+    if (mat.soil_dry) mat.soil_dry += b0o;
+  }
   // Per-sample constants are staged through LDS, 32 samples (6 KB fp32) at a time: one coalesced copy by the
   // workgroup, then every wave reads sample s's 48 values with wave-uniform ds_read_b128 (a broadcast).  They
   // land in VGPRs: on gfx950 a VALU op with an SGPR source issues ~1.6x slower than with VGPR / literal sources
@@ -159,7 +187,7 @@ __global__ __launch_bounds__(TILE) void k_bands(const T* __restrict__ tab, const
     T refl, tran, absb, K;
     leaf_band<T>(tb, c[C_CAB], c[C_CCA], c[C_CDM], c[C_CW], c[C_CS], c[C_CANT], c[C_CBC], c[C_PROT], c[C_NM1], refl,
                  tran, absb, K);
-    T rdry = (MAT && mat.rdry_in) ? mat.rdry_in[s * NWL + ti] : soil_dry<T>(tb, c[C_F1], c[C_F2], c[C_F3]);
+    T rdry = (MAT == 2) ? mat.rdry_in[s * mat.po + ti] : soil_dry<T>(tb, c[C_F1], c[C_F2], c[C_F3]);
     T fm[7] = {c[C_FM0], c[C_FM1], c[C_FM2], c[C_FM3], c[C_FM4], c[C_FM5], c[C_FM6]};
     T rwet;
     soil_band<T>(tb, rdry, c[C_WET], fm, c[C_FMSUM], c[C_FILM2L], rwet);
@@ -181,20 +209,16 @@ __global__ __launch_bounds__(TILE) void k_bands(const T* __restrict__ tab, const
     }
     if (MAT) {
       if (active) {
-        // row pointers are wave-uniform (scalar arithmetic); the lane only adds its 32-bit band offset, so the
-        // stores use the SGPR-base + VGPR-offset form and need no 64-bit VALU address math
-        const int64_t ro = s * NWLS;                   // band 2001 = first thermal position
-        if (mat.leaf_refl) (mat.leaf_refl + ro)[band] = rho;
-        if (mat.leaf_tran) (mat.leaf_tran + ro)[band] = tau;
-        if (mat.soil_refl) (mat.soil_refl + ro)[band] = rwet;
-        if (mat.rso) (mat.rso + ro)[band] = rso;
-        if (mat.rdo) (mat.rdo + ro)[band] = rdo;
-        if (mat.rsd) (mat.rsd + ro)[band] = rsd;
-        if (mat.rdd) (mat.rdd + ro)[band] = rdd;
+        if (mat.leaf_refl) store_row(mat.leaf_refl, off_f, rho);
+        if (mat.leaf_tran) store_row(mat.leaf_tran, off_f, tau);
+        if (mat.soil_refl) store_row(mat.soil_refl, off_f, rwet);
+        if (mat.rso) store_row(mat.rso, off_f, rso);
+        if (mat.rdo) store_row(mat.rdo, off_f, rdo);
+        if (mat.rsd) store_row(mat.rsd, off_f, rsd);
+        if (mat.rdd) store_row(mat.rdd, off_f, rdd);
         if (!thermal) {
-          const int64_t r1 = s * NWL;
-          if (mat.leaf_kchl) (mat.leaf_kchl + r1)[band] = (K > T(0)) ? divx(c[C_CAB] * tb.kab, K) : T(0);  // prospect_5d.py:197-198
-          if (mat.soil_dry) (mat.soil_dry + r1)[band] = rdry;
+          if (mat.leaf_kchl) store_row(mat.leaf_kchl, off_o, (K > T(0)) ? divx(c[C_CAB] * tb.kab, K) : T(0));  // prospect_5d.py:197-198
+          if (mat.soil_dry) store_row(mat.soil_dry, off_o, rdry);
         }
         if (mat.gsoil && slot >= 0) (mat.gsoil + s * nslot)[slot] = rwet;
       }
@@ -202,21 +226,23 @@ __global__ __launch_bounds__(TILE) void k_bands(const T* __restrict__ tab, const
       // bands 2002..2161 of the padded spectra -- 160 values per array, three coalesced stores per lane
       constexpr int TH_WAVE = (NWL % TILE) / 64, TH_LANE = (NWL % TILE) % 64;
       if (tile == NTILE - 1 && (int)(threadIdx.x >> 6) == TH_WAVE) {
-        const int l = threadIdx.x & 63;
-        const int64_t ro = s * NWLS + NWL + 1;
+        // this lane's band is 1792 + 192 + l; the pad starts at band 2002 = this wave's row offset + (TH_LANE + 1 + l)
+        const unsigned pad = off_f + (unsigned)((TH_LANE + 1) * (int)sizeof(T));
         T* arrs[7] = {mat.leaf_refl, mat.leaf_tran, mat.soil_refl, mat.rso, mat.rdo, mat.rsd, mat.rdd};
         const T vals[7] = {rho, tau, rwet, rso, rdo, rsd, rdd};
+        const int l = threadIdx.x & 63;
 #pragma unroll
         for (int q = 0; q < 7; ++q) {
           const T v = __shfl(vals[q], TH_LANE, 64);
           if (arrs[q]) {
-            T* dst = arrs[q] + ro;
-            dst[l] = v;
-            dst[64 + l] = v;
-            if (l < NWLT - 1 - 128) dst[128 + l] = v;
+            store_row(arrs[q], pad, v);
+            store_row(arrs[q], pad + 64u * (unsigned)sizeof(T), v);
+            if (l < NWLT - 1 - 128) store_row(arrs[q], pad + 128u * (unsigned)sizeof(T), v);
           }
         }
       }
+      off_f += (unsigned)mat.pf * (unsigned)sizeof(T);
+      off_o += (unsigned)mat.po * (unsigned)sizeof(T);
     }
   }
   }
@@ -276,8 +302,8 @@ __global__ __launch_bounds__(256) void k_bandmean(const T* __restrict__ bandsum,
 // standalone PROSPECT-5D / PRO: (B,2001) spectra out
 template <typename T>
 __global__ __launch_bounds__(TILE) void k_prospect(const T* __restrict__ tab, const T* __restrict__ cst, int64_t B,
-                                                   int chunk, T* __restrict__ o_refl, T* __restrict__ o_tran,
-                                                   T* __restrict__ o_kchl) {
+                                                   int chunk, int po, T* __restrict__ o_refl,
+                                                   T* __restrict__ o_tran, T* __restrict__ o_kchl) {
   int tile;
   int64_t ck;
   xcd_map(blockIdx.x, tile, ck);
@@ -293,7 +319,7 @@ __global__ __launch_bounds__(TILE) void k_prospect(const T* __restrict__ tab, co
     leaf_band<T>(tb, c[C_CAB], c[C_CCA], c[C_CDM], c[C_CW], c[C_CS], c[C_CANT], c[C_CBC], c[C_PROT], c[C_NM1], refl,
                  tran, absb, K);
     if (active) {
-      const int64_t o = s * NWL + band;
+      const int64_t o = s * po + band;
       if (o_refl) o_refl[o] = refl;
       if (o_tran) o_tran[o] = tran;
       if (o_kchl) o_kchl[o] = (K > T(0)) ? divx(c[C_CAB] * tb.kab, K) : T(0);
@@ -304,8 +330,8 @@ __global__ __launch_bounds__(TILE) void k_prospect(const T* __restrict__ tab, co
 // standalone BSM: (B,2001) wet and dry soil spectra; optional user dry spectra (bsm.py:42-43)
 template <typename T>
 __global__ __launch_bounds__(TILE) void k_bsm(const T* __restrict__ tab, const T* __restrict__ cst, int64_t B,
-                                              int chunk, const T* __restrict__ rdry_in, T* __restrict__ o_refl,
-                                              T* __restrict__ o_dry) {
+                                              int chunk, int po, const T* __restrict__ rdry_in,
+                                              T* __restrict__ o_refl, T* __restrict__ o_dry) {
   int tile;
   int64_t ck;
   xcd_map(blockIdx.x, tile, ck);
@@ -317,12 +343,12 @@ __global__ __launch_bounds__(TILE) void k_bsm(const T* __restrict__ tab, const T
   const int64_t s1 = (s0 + chunk < B) ? s0 + chunk : B;
   for (int64_t s = s0; s < s1; ++s) {
     const T* __restrict__ c = cst + s * NCONST;
-    T rdry = rdry_in ? (active ? rdry_in[s * NWL + band] : T(0)) : soil_dry<T>(tb, c[C_F1], c[C_F2], c[C_F3]);
+    T rdry = rdry_in ? (active ? rdry_in[s * po + band] : T(0)) : soil_dry<T>(tb, c[C_F1], c[C_F2], c[C_F3]);
     T fm[7] = {c[C_FM0], c[C_FM1], c[C_FM2], c[C_FM3], c[C_FM4], c[C_FM5], c[C_FM6]};
     T rwet;
     soil_band<T>(tb, rdry, c[C_WET], fm, c[C_FMSUM], c[C_FILM2L], rwet);
     if (active) {
-      const int64_t o = s * NWL + band;
+      const int64_t o = s * po + band;
       if (o_refl) o_refl[o] = rwet;
       if (o_dry) o_dry[o] = rdry;
     }
@@ -331,7 +357,7 @@ __global__ __launch_bounds__(TILE) void k_bsm(const T* __restrict__ tab, const T
 
 // standalone SAILH: leaf / soil spectra in, four canopy reflectance spectra out, all (B,2162)
 template <typename T>
-__global__ __launch_bounds__(TILE) void k_sailh(const T* __restrict__ cst, int64_t B, int chunk,
+__global__ __launch_bounds__(TILE) void k_sailh(const T* __restrict__ cst, int64_t B, int chunk, int pf,
                                                 const T* __restrict__ i_rho, const T* __restrict__ i_tau,
                                                 const T* __restrict__ i_rs, T* __restrict__ o_rso,
                                                 T* __restrict__ o_rdo, T* __restrict__ o_rsd, T* __restrict__ o_rdd) {
@@ -343,7 +369,7 @@ __global__ __launch_bounds__(TILE) void k_sailh(const T* __restrict__ cst, int64
   const int64_t s1 = (s0 + chunk < B) ? s0 + chunk : B;
   for (int64_t s = s0; s < s1; ++s) {
     const T* __restrict__ c = cst + s * NCONST;
-    const int64_t o = s * NWLS + (active ? band : 0);
+    const int64_t o = s * pf + (active ? band : 0);
     T rho = i_rho[o], tau = i_tau[o], rs = i_rs[o];
     const CanopyPar<T> cp = load_canopy(c);
     T rso, rdo, rsd, rdd;

@@ -27,8 +27,15 @@ def _dp(a):
     return a.ctypes.data_as(_lib.c_dp)
 
 
+# Row pitch (elements) of the (B,2162) / (B,2001) spectrum arrays: rows padded to a multiple of 64 elements start
+# on the 128 B line grid, which nearly doubles the HBM store rate of the materialised spectra on MI355X
+# (include/spart_hip.h: spart_ctx_set_row_pitch).  Spectra are returned as [:, :width] views of padded storage.
+ROW_PITCH = (2176, 2048)
+
+
 class Engine:
-    def __init__(self, sensor=None, device=0, sensor_info=None, lib_path=None):
+    def __init__(self, sensor=None, device=0, sensor_info=None, lib_path=None, row_pitch=ROW_PITCH):
+        """row_pitch: (pitch of 2162-wide rows, pitch of 2001-wide rows) or None for dense arrays."""
         torch = _require_gpu()
         self.lib = _lib.load(lib_path)
         self.torch = torch
@@ -61,6 +68,11 @@ class Engine:
         _lib.check(self.lib, None, rc)
         self.ctx = ctx
         self._ws_buf = None
+        self.row_pitch = {_lib.NWLS: _lib.NWLS, _lib.NWL: _lib.NWL}
+        if row_pitch is not None:
+            pf, po = int(row_pitch[0]), int(row_pitch[1])
+            _lib.check(self.lib, self.ctx, self.lib.spart_ctx_set_row_pitch(self.ctx, pf, po))
+            self.row_pitch = {_lib.NWLS: pf, _lib.NWL: po}
 
     def __del__(self):
         try:
@@ -105,7 +117,13 @@ class Engine:
     def _tdtype(self, dt):
         return self.torch.float32 if dt == _lib.SPART_F32 else self.torch.float64
 
+    def _alloc_spec(self, B, width, td):
+        """(B, width) spectrum array on this context's row pitch (a view of padded storage when pitch > width)."""
+        pitch = self.row_pitch[width]
+        return self.torch.empty((B, pitch), dtype=td, device=self.device)[:, :width]
+
     def _spec(self, x, B, width, dt):
+        """input spectra -> (B, width) device tensor of dtype dt on this context's row pitch."""
         torch = self.torch
         if not torch.is_tensor(x):
             x = torch.as_tensor(np.asarray(x))
@@ -119,7 +137,11 @@ class Engine:
             if x.shape[0] != 1:
                 raise ValueError("spectra do not broadcast to the batch")
             x = x.expand(B, width)
-        return x.contiguous()
+        if x.stride() == (self.row_pitch[width], 1):
+            return x
+        buf = self._alloc_spec(B, width, x.dtype)
+        buf.copy_(x)
+        return buf
 
     # ------------------------------------------------------------------ operators
     def prospect(self, leaf9, dtype="float64"):
@@ -127,7 +149,7 @@ class Engine:
         dt = DTYPES[dtype]
         cols, B = self.columns(leaf9)
         td = self._tdtype(dt)
-        out = [self.torch.empty((B, _lib.NWL), dtype=td, device=self.device) for _ in range(3)]
+        out = [self._alloc_spec(B, _lib.NWL, td) for _ in range(3)]
         ws, wsn = self._workspace(dt, B)
         rc = self.lib.spart_prospect_batch(self.ctx, dt, B, self._ptrs(cols), out[0].data_ptr(), out[1].data_ptr(),
                                            out[2].data_ptr(), ws, wsn, self._stream())
@@ -148,7 +170,7 @@ class Engine:
             cols = [c.expand(B).contiguous() if c.numel() == 1 else c for c in cols]
             rd = self._spec(rdry, B, _lib.NWL, dt)
         td = self._tdtype(dt)
-        out = [self.torch.empty((B, _lib.NWL), dtype=td, device=self.device) for _ in range(2)]
+        out = [self._alloc_spec(B, _lib.NWL, td) for _ in range(2)]
         ws, wsn = self._workspace(dt, B)
         rc = self.lib.spart_bsm_batch(self.ctx, dt, B, self._ptrs(cols), rd.data_ptr() if rd is not None else None,
                                       out[0].data_ptr(), out[1].data_ptr(), ws, wsn, self._stream())
@@ -173,7 +195,7 @@ class Engine:
         cols = [c.expand(B).contiguous() if c.numel() == 1 else c for c in cols]
         rho, tau, rs = (self._spec(x, B, _lib.NWLS, dt) for x in (rho, tau, rs))
         td = self._tdtype(dt)
-        out = [self.torch.empty((B, _lib.NWLS), dtype=td, device=self.device) for _ in range(4)]
+        out = [self._alloc_spec(B, _lib.NWLS, td) for _ in range(4)]
         ws, wsn = self._workspace(dt, B)
         rc = self.lib.spart_sailh_batch(self.ctx, dt, B, rho.data_ptr(), tau.data_ptr(), rs.data_ptr(),
                                         self._ptrs(cols[:4]), self._ptrs(cols[4:]), self._ptrs(out), ws, wsn,
@@ -238,8 +260,11 @@ class Engine:
             for name in materialize:
                 if name not in MATERIALIZE_FIELDS:
                     raise ValueError(f"unknown materialize field {name}")
-                shape = (4, _lib.NWLS) if name == "band_mean" else (B, _MAT_WIDTH.get(name, self.nb))
-                res[name] = torch.empty(shape, dtype=td, device=self.device)
+                if name in _MAT_WIDTH:
+                    res[name] = self._alloc_spec(B, _MAT_WIDTH[name], td)
+                else:
+                    res[name] = torch.empty((4, _lib.NWLS) if name == "band_mean" else (B, self.nb), dtype=td,
+                                            device=self.device)
                 setattr(mat, name, res[name].data_ptr())
         ws, wsn = self._workspace(dt, B)
         rc = self.lib.spart_run_batch(self.ctx, dt, B, self._ptrs(cols), th[0].data_ptr() if th[0] is not None else None,
