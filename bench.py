@@ -20,6 +20,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "spart-python_amd"))
 
+PROFILE_TAG = "r1_g"      # profiles/<tag>_traffic.json, <tag>_valu.json: the committed rocprofv3 PMC passes of this build
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_VALU_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector
 
@@ -32,10 +33,10 @@ def algorithmic_bytes(nb, dtype):
 
 def measured_traffic(kernel):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r1_f_traffic.json; FETCH_SIZE and WRITE_SIZE need separate passes, so this cannot be
+    (profiles/<PROFILE_TAG>_traffic.json; FETCH_SIZE and WRITE_SIZE need separate passes, so this cannot be
     collected live).  None when the profile does not cover this kernel / batch."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r1_f_traffic.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", PROFILE_TAG + "_traffic.json")))
         for k, v in d.items():
             if k.replace(" ", "") == "spart::" + kernel.replace(" ", ""):
                 return v["hbm_bytes_per_launch"]
@@ -59,6 +60,19 @@ def _cpu_worker(job):
     for i in range(0, len(P), 256):
         O.spart_run(P[i:i + 256], sensor, T, **kw)
     return time.perf_counter() - t0
+
+
+def measured_valu(kern_s):
+    """VALU issue figures of the band kernel from the committed SQ counter pass (profiles/<PROFILE_TAG>_valu.json):
+    wave-instructions per launch, and the fraction of the chip's VALU issue slots they fill at the 2-cycle wave64
+    fp32 cadence (1024 SIMDs, 2.4 GHz peak clock) over the launch duration measured in THIS run."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", PROFILE_TAG + "_valu.json")))
+        n, t = d["SQ_INSTS_VALU"], d.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
+        return {"wave_insts_per_launch": n, "transcendental_wave_insts": t,
+                "issue_frac": n * 2.0 / (1024 * 2.4e9 * kern_s)}
+    except Exception:
+        return {}
 
 
 def cpu_baseline(sensor, rows_per_core, seed):
@@ -185,6 +199,7 @@ def main():
         value = total / dt
         kern_s = band_ms / max(ncalls, 1) / 1e3
         abytes = algorithmic_bytes(nb, args.dtype) * B          # per launch of the band kernel's step
+        std = args.dtype == "float32" and B == 1_000_000 and args.sensor == "Sentinel2A-MSI"   # the profiled configuration
         achieved = abytes / kern_s / 1e9
         line = {
             "metric": "SPART spectra/sec (R_TOC+R_TOA+L_TOA) at batch 1M; achieved HBM GB/s vs peak",
@@ -199,13 +214,14 @@ def main():
                        "input_dtype": "f64", "finite": ok},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic("k_bands<float,false,true>") if (args.dtype == "float32" and B == 1_000_000 and args.sensor == "Sentinel2A-MSI") else None,
-                         "kernel": "k_bands<float,false,true>" if args.dtype == "float32" else "k_bands<double,false,true>",
+                         "traffic": measured_traffic("k_bands<float,0,true>") if std else None,
+                         "kernel": "k_bands<float,0,true>" if args.dtype == "float32" else "k_bands<double,0,true>",
                          "kernel_ms": kern_s * 1e3, "algorithmic_bytes_per_spectrum": algorithmic_bytes(nb, args.dtype),
                          "note": "fused path is VALU/transcendental bound by design (SURVEY.md §8d); HBM fraction is "
                                  "reported because the metric asks for it",
-                         "valu": {"flop_eq_per_spectrum": 8.7e5,
-                                  "achieved_tflop_eq": 8.7e5 * B / kern_s / 1e12, "peak_fp32_tflops": FP32_VALU_TFLOPS}},
+                         "valu": dict({"flop_eq_per_spectrum": 8.7e5,
+                                       "achieved_tflop_eq": 8.7e5 * B / kern_s / 1e12, "peak_fp32_tflops": FP32_VALU_TFLOPS},
+                                      **(measured_valu(kern_s) if std else {}))},
         }
         line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)

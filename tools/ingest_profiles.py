@@ -24,6 +24,23 @@ res["_note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over
 json.dump(res, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
 shutil.copy(glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
 shutil.copy(glob.glob(os.path.join(src, "pmc_sq", "*", "*_counter_collection.csv"))[0], os.path.join(dst, f"{tag}_pmc_sq_counter_collection.csv"))
+# per-launch SQ counters of the band kernel -> <tag>_valu.json (read by bench.py for roofline.valu)
+sq = collections.defaultdict(lambda: collections.defaultdict(float))
+for r in csv.DictReader(open(os.path.join(dst, f"{tag}_pmc_sq_counter_collection.csv"))):
+    if "k_bands" in r["Kernel_Name"]:
+        sq[r["Dispatch_Id"]][r["Counter_Name"]] += float(r["Counter_Value"])
+if sq:
+    names = sorted(next(iter(sq.values())))
+    avg = {n: sum(d[n] for d in sq.values()) / len(sq) for n in names}
+    avg["_note"] = ("per launch of the band kernel (B = 1M, fp32), summed over all XCDs / SEs; GRBM_GUI_ACTIVE is the sum over the 8 XCDs "
+                    "(divide by 8 for the kernel's cycles)")
+    json.dump(avg, open(os.path.join(dst, f"{tag}_valu.json"), "w"), indent=1)
+for d in ("mat_stats", "mat_pmc_write"):
+    g = glob.glob(os.path.join(src, d, "*", "*_kernel_stats.csv" if d == "mat_stats" else "*_counter_collection.csv"))
+    if g:
+        shutil.copy(g[0], os.path.join(dst, f"{tag}_{d}.csv"))
+if os.path.exists(os.path.join(src, "mat_bench.txt")):
+    shutil.copy(os.path.join(src, "mat_bench.txt"), os.path.join(dst, f"{tag}_mat_bench.txt"))
 shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, f"{tag}_bench.json"))
 shutil.copy(os.path.join(src, "configs.json"), os.path.join(dst, f"{tag}_configs.json"))
 print(json.dumps({k: v for k, v in res.items() if k != "_note"}, indent=1))
