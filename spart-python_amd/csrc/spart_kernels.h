@@ -136,9 +136,12 @@ template <typename T> struct MatPtrs {
 // MAT: 0 = sensor columns only; 1 = also store the requested full spectra; 2 = 1 + per-sample dry-soil spectra are
 // READ (rdry_in).  The read is its own variant because a global load inside the sample loop makes the compiler wait
 // for vmcnt(0) -- i.e. for every outstanding store of the previous sample -- once per sample, which serialises the
-// store stream with the arithmetic (materialised mode 3.4 -> 5.x TB/s without it).
+// store stream with the arithmetic.
+// fp64: left alone hipcc takes 262 VGPRs = ONE wave per SIMD; asking for two workgroups per CU (256 VGPRs, 7 spilled)
+// makes the fp64 mode 24 % faster (50.7 -> 38.6 ms per 1M spectra); three (168 VGPRs, 96 spilled) is 2.7x slower.
 template <typename T, int MAT, bool FULL>
-__global__ __launch_bounds__(TILE) void k_bands(const T* __restrict__ tab, const T* __restrict__ cst,
+__global__ __launch_bounds__(TILE, (sizeof(T) == 8 ? 2 : 1))
+void k_bands(const T* __restrict__ tab, const T* __restrict__ cst,
                                                 const int* __restrict__ need_slot, int nslot, T* __restrict__ G,
                                                 int64_t B, int chunk, MatPtrs<T> mat, T* __restrict__ bandsum) {
   int tile;
