@@ -1,6 +1,6 @@
 """Look-up-table generation: stream a large parameter table through the GPU in chunks and land the sensor
-columns in host memory / on disk.  The host<->device copies of chunk i+1 / i-1 run on their
-own HIP streams beside the kernels of chunk i (double-buffered pinned staging), so the PCIe traffic
+columns in host memory / on disk.  The host<->device copies of chunk i+1 / i run on their
+own HIP streams beside the kernels (double-buffered device buffers, no host staging copy), so the PCIe traffic
 (216 B in + 3*nb*4 B out per spectrum) hides behind the evaluation whenever the link keeps up.
 
 On-disk layout (a directory):
@@ -22,7 +22,18 @@ COLUMNS = ("R_TOC", "R_TOA", "L_TOA")
 
 def generate_lut(params, sensor, path=None, dtype="float32", chunk=1 << 20, device=None, prune=False):
     """params: (B, 27) array-like on the HOST (numpy / memmap).  Returns dict of host arrays (np.memmap when
-    ``path`` is given).  ``prune=True`` evaluates only the bands the sensor needs (identical columns)."""
+    ``path`` is given).  ``prune=True`` evaluates only the bands the sensor needs (identical columns).
+
+    Pipeline per chunk i (three HIP streams; the host never holds a private staging copy):
+        upload(i+1)   H2D of the next (n, 27) rows straight from the caller's table + on-device transpose to the
+                      structure-of-arrays layout the kernels read          -- overlaps the kernels of chunk i
+        launch(i+1)   queued behind chunk i on the compute stream
+        download(i)   D2H of the three (n, nb) column blocks straight into the destination arrays / memmaps
+                                                                            -- overlaps the kernels of chunk i+1
+    The copies block the HOST thread (pageable memory) but not the GPU, which stays busy as long as the two copies
+    of a chunk (372 B per spectrum, ~7 ms per 1M at PCIe Gen5 rates) take less than its kernels (12 ms per 1M)."""
+    import warnings
+
     import torch
 
     P = np.asarray(params) if not isinstance(params, np.memmap) else params
@@ -45,64 +56,75 @@ def generate_lut(params, sensor, path=None, dtype="float32", chunk=1 << 20, devi
     dev = eng.device
     compute = torch.cuda.current_stream(dev)
     h2d, d2h = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
-    # double-buffered staging: pinned host + device, for parameters in and columns out
-    hin = [torch.empty((chunk, workloads.NPARAM), dtype=torch.float64).pin_memory() for _ in range(2)]
-    din = [torch.empty((workloads.NPARAM, chunk), dtype=torch.float64, device=dev) for _ in range(2)]
+    drow = [torch.empty((chunk, workloads.NPARAM), dtype=torch.float64, device=dev) for _ in range(2)]   # as on the host
+    dsoa = [torch.empty((workloads.NPARAM, chunk), dtype=torch.float64, device=dev) for _ in range(2)]   # kernel layout
     dout = [torch.empty((3, chunk, nb), dtype=tdt, device=dev) for _ in range(2)]
-    hout = [torch.empty((3, chunk, nb), dtype=tdt).pin_memory() for _ in range(2)]
     ev_in = [torch.cuda.Event() for _ in range(2)]
     ev_done = [torch.cuda.Event() for _ in range(2)]
-    ev_out = [torch.cuda.Event() for _ in range(2)]
-    ev_free = [torch.cuda.Event() for _ in range(2)]
-    pending = [None, None]          # (lo, n) whose columns sit in hout[j] once ev_out[j] has passed
     nchunks = (B + chunk - 1) // chunk
+    keep = [None, None]         # host source of the upload in flight on buffer j (a temporary when P needed converting)
 
-    def stage_in(i):
-        j = i % 2
+    def bounds(i):
         lo = i * chunk
-        n = min(chunk, B - lo)
-        hin[j][:n].copy_(torch.from_numpy(np.ascontiguousarray(P[lo:lo + n], dtype=np.float64)))
-        if pm is not None:
-            pm[lo:lo + n] = hin[j][:n].numpy()
-        with torch.cuda.stream(h2d):
-            h2d.wait_event(ev_free[j]) if i >= 2 else None        # din[j] is free once chunk i-2's kernels ran
-            tmp = hin[j][:n].to(dev, non_blocking=True)           # (n, 27)
-            din[j][:, :n].copy_(tmp.t())                          # -> structure of arrays (27, n)
-            ev_in[j].record(h2d)
-        return lo, n
+        return lo, min(chunk, B - lo)
 
-    def drain(j):
-        if pending[j] is not None:
-            lo, n = pending[j]
-            ev_out[j].synchronize()
-            for q, k in enumerate(COLUMNS):
-                out[k][lo:lo + n] = hout[j][q, :n].numpy()
-            pending[j] = None
+    def as_tensor(a):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")          # read-only inputs (memmaps opened "r") are only read
+            return torch.from_numpy(a)
 
-    if nchunks:
-        nxt = stage_in(0)
-    for i in range(nchunks):
+    def upload(i):
         j = i % 2
-        lo, n = nxt
-        if i + 1 < nchunks:
-            nxt = stage_in(i + 1)                                  # overlaps with the kernels below
-        drain(j)                                                   # hout[j] / dout[j] from chunk i-2 must be consumed
+        lo, n = bounds(i)
+        src = P[lo:lo + n]
+        if src.dtype != np.float64 or not src.flags.c_contiguous:
+            src = np.ascontiguousarray(src, dtype=np.float64)
+        with torch.cuda.stream(h2d):
+            if i >= 2:
+                h2d.wait_event(ev_done[j])                         # dsoa[j] is free once chunk i-2's kernels ran
+            keep[j] = src
+            drow[j][:n].copy_(as_tensor(src), non_blocking=True)
+            dsoa[j][:, :n].copy_(drow[j][:n].t())                  # -> structure of arrays (27, n)
+            ev_in[j].record(h2d)
+        if pm is not None:
+            pm[lo:lo + n] = src
+
+    def launch(i):
+        j = i % 2
+        lo, n = bounds(i)
         compute.wait_event(ev_in[j])
         res = dout[j][:, :n]
-        if din[j].shape[1] == n:
-            Pd = din[j]
-        else:
-            Pd = din[j][:, :n].contiguous()
+        Pd = dsoa[j] if n == chunk else dsoa[j][:, :n].contiguous()
         eng.run(Pd, dtype, out={"R_TOC": res[0], "R_TOA": res[1], "L_TOA": res[2]}, prune=prune)
         ev_done[j].record(compute)
-        ev_free[j].record(compute)
-        with torch.cuda.stream(d2h):
+
+    def download(i):                                               # runs on the helper thread
+        j = i % 2
+        lo, n = bounds(i)
+        with torch.cuda.device(dev), torch.cuda.stream(d2h):
             d2h.wait_event(ev_done[j])
-            hout[j][:, :n].copy_(res, non_blocking=True)
-            ev_out[j].record(d2h)
-        pending[j] = (lo, n)
-    drain(0)
-    drain(1)
+            for q, k in enumerate(COLUMNS):
+                as_tensor(out[k][lo:lo + n]).copy_(dout[j][q, :n], non_blocking=True)
+            d2h.synchronize()                                      # dout[j] may be overwritten by chunk i+2
+
+    # downloads (which also take the first-touch page faults of the destination) run on one helper thread so that
+    # they overlap the uploads issued by this thread; torch releases the GIL inside the copies
+    from concurrent.futures import ThreadPoolExecutor
+    fut = [None, None]
+    with ThreadPoolExecutor(1) as pool:
+        if nchunks:
+            upload(0)
+            launch(0)
+        for i in range(nchunks):
+            if i + 1 < nchunks:
+                upload(i + 1)                                      # overlaps the kernels of chunk i
+                if fut[(i + 1) % 2] is not None:
+                    fut[(i + 1) % 2].result()                      # dout[(i+1) % 2] has been drained (chunk i-1)
+                launch(i + 1)
+            fut[i % 2] = pool.submit(download, i)                  # overlaps the kernels of chunk i+1
+        for f in fut:
+            if f is not None:
+                f.result()
     if path is not None:
         for a in out.values():
             a.flush()
