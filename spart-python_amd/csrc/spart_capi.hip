@@ -261,6 +261,8 @@ static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_
   if (mat && (int64_t)chunk * (int64_t)ctx->pf * (int64_t)sizeof(T) > (int64_t)3900000000LL)
     return fail(ctx, SPART_ERR_INVALID, "batch too large for materialised spectra in one call (chunk %d rows x pitch %d)", chunk, ctx->pf);
   const bool full = !(opt && opt->prune_unused_bands);
+  if (opt && opt->band_mean && !full)
+    return fail(ctx, SPART_ERR_INVALID, "spart_run_batch: band_mean needs prune_unused_bands = 0");
   const bool prof = ctx->profile && ctx->ev_used + 2 <= ctx->ev.size();
   if (prof) HIP_TRY(ctx, hipEventRecord(ctx->ev[ctx->ev_used], st));
 #define SPART_LAUNCH_BANDS(M, F)                                                                                 \
@@ -283,7 +285,6 @@ static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_
     ctx->ev_used += 2;
   }
   if (opt && opt->band_mean) {
-    if (!full) return fail(ctx, SPART_ERR_INVALID, "spart_run_batch: band_mean needs prune_unused_bands = 0");
     hipLaunchKernelGGL((k_bandmean<T>), dim3((4 * NWLS + 255) / 256), dim3(256), 0, st, (const T*)bsum, nchunk, B,
                        (T*)opt->band_mean);
     HIP_TRY(ctx, hipGetLastError());

@@ -137,10 +137,8 @@ template <> struct Mx<float> {
     return -::expm1f(-z);
 #endif
   }
-  static SPART_HD float expm1(float x) { return ::expm1f(x); }
   static SPART_HD float fabs(float x) { return ::fabsf(x); }
   static SPART_HD float fmax(float a, float b) { return ::fmaxf(a, b); }
-  static SPART_HD float fmin(float a, float b) { return ::fminf(a, b); }
   static SPART_HD float tiny() { return 1e-30f; }
 };
 
@@ -208,25 +206,16 @@ template <> struct Mx<double> {
     return -::expm1(-z);
 #endif
   }
-  static SPART_HD double expm1(double x) { return ::expm1(x); }
   static SPART_HD double fabs(double x) { return ::fabs(x); }
   static SPART_HD double fmax(double a, double b) { return ::fmax(a, b); }
-  static SPART_HD double fmin(double a, double b) { return ::fmin(a, b); }
   static SPART_HD double tiny() { return 1e-300; }
 };
 
 template <typename T> SPART_HD T divx(T a, T b) { return a * Mx<T>::rcp(b); }
 
-// phi(d) = (1 - e^-d) / d   (-> 1 as d -> 0); the building block of the SAIL J-functions
-template <typename T> SPART_HD T phi_fn(T d) {
-  const T small = T(1e-10);  // expm1 is accurate for every d != 0; this only removes 0/0
-  T safe = (Mx<T>::fabs(d) < small) ? T(1) : d;
-  T v = -Mx<T>::expm1(-safe) * Mx<T>::rcp(safe);
-  return (Mx<T>::fabs(d) < small) ? (T(1) - T(0.5) * d) : v;
-}
-
 // SAIL J-functions (sailh.py:154-183) for x = -1 / x = 0:
-//   J1 = (e^-mL - e^-kL)/(k - m) = L e^-kL phi((m-k)L),   J2 = (1 - e^-kL e^-mL)/(k + m) = L phi((k+m)L)
+//   J1 = (e^-mL - e^-kL)/(k - m) = L e^-kL phi((m-k)L),   J2 = (1 - e^-kL e^-mL)/(k + m) = L phi((k+m)L),
+//   phi(d) = (1 - e^-d)/d  (-> 1 as d -> 0)
 // e1 = exp(-m L) is shared between the four of them; below |d| < THRESH the Taylor polynomial of phi replaces
 // the difference of nearly equal exponentials (float: 0.06, next term d^5/720 = 1e-9).
 template <typename T> struct SailJ;
