@@ -400,3 +400,36 @@ def test_user_dry_soil_spectra_full_chain(golden, dtype, torch_mod):
     cols[9] = cols[10] = cols[11] = None
     out = eng.run(cols, dtype, rdry=g["spectra"], materialize=("soil_refl_dry",))
     assert rel_err(out["soil_refl_dry"].cpu().numpy(), g["spectra"], 1e-3) < 1e-6
+
+
+def test_row_pitch_dense_and_padded_agree(torch_mod):
+    """spart_ctx_set_row_pitch: the padded default (rows on the 128 B line grid) and the dense layout give
+    bit-identical spectra through every entry point that reads or writes (B,2162) / (B,2001) arrays, including
+    spectra handed back in as inputs (strided views and dense copies)."""
+    from spart_amd import workloads
+    from spart_amd.engine import Engine, ROW_PITCH
+    pad, dense = Engine("Sentinel2A-MSI", 0), Engine("Sentinel2A-MSI", 0, row_pitch=None)
+    B = 333
+    P = torch_mod.as_tensor(workloads.lhs_params(B, "full", seed=11).T.copy(), device="cuda:0")
+    fields = ("leaf_refl", "leaf_tran", "leaf_kchl", "soil_refl", "soil_refl_dry", "rso", "rdo", "rsd", "rdd")
+    for dtype in ("float32", "float64"):
+        a, b = pad.run(P, dtype, materialize=fields), dense.run(P, dtype, materialize=fields)
+        assert a["rso"].stride() == (ROW_PITCH[0], 1) and a["leaf_kchl"].stride() == (ROW_PITCH[1], 1)
+        assert b["rso"].is_contiguous()
+        for k in fields + ("R_TOC", "R_TOA", "L_TOA"):
+            assert torch_mod.equal(a[k], b[k]), (dtype, k)
+        la, lb = pad.prospect([P[i] for i in range(9)], dtype), dense.prospect([P[i] for i in range(9)], dtype)
+        sa, sb = pad.bsm([P[i] for i in range(9, 15)], dtype), dense.bsm([P[i] for i in range(9, 15)], dtype)
+        assert all(torch_mod.equal(x, y) for x, y in zip(la + sa, lb + sb))
+        # spectra back in: the padded engine takes its own strided outputs as they are, the dense engine's
+        # contiguous ones through a re-pitching copy; user dry-soil spectra likewise
+        can, ang = [P[i] for i in range(15, 19)], [P[i] for i in range(19, 22)]
+        ca = pad.sailh(a["leaf_refl"], a["leaf_tran"], a["soil_refl"], can, ang, dtype)
+        cb = dense.sailh(b["leaf_refl"], b["leaf_tran"], b["soil_refl"], can, ang, dtype)
+        cc = pad.sailh(b["leaf_refl"], b["leaf_tran"], b["soil_refl"], can, ang, dtype)
+        for x, y, z in zip(ca, cb, cc):
+            assert torch_mod.equal(x, y) and torch_mod.equal(x, z)
+        ra = pad.run(P, dtype, rdry=sa[1], materialize=("soil_refl",))
+        rb = dense.run(P, dtype, rdry=sb[1], materialize=("soil_refl",))
+        for k in ("soil_refl", "R_TOC", "R_TOA", "L_TOA"):
+            assert torch_mod.equal(ra[k], rb[k]), (dtype, k)
