@@ -46,12 +46,18 @@ def build(force=False, fast_math=None, verbose=True, out=None, extra=()):
         fast_math = os.environ.get("SPART_FAST_MATH", "1") == "1"   # default: hardware rcp/exp/log/sqrt (parity-tested)
     if not force and not needs_build():
         return OUT
-    cmd = [hipcc(), *FLAGS, "-o", OUT, SRC]
+    tmp = f"{OUT}.tmp.{os.getpid()}"      # several ranks may get here at once: each links its own file, the rename is atomic
+    cmd = [hipcc(), *FLAGS, "-o", tmp, SRC]
     if fast_math:
         cmd.insert(1, "-DSPART_FAST_MATH=1")
     if verbose:
         print("[spart_amd] " + " ".join(cmd), file=sys.stderr, flush=True)
-    subprocess.check_call(cmd)
+    try:
+        subprocess.check_call(cmd)
+        os.replace(tmp, OUT)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return OUT
 
 
