@@ -122,3 +122,19 @@ def test_engine_input_validation_messages():
         SPART.SoilParametersFromFile("some_file.txt", 20, 25, 0.015)      # JPL text parsing is out of scope
     s = SPART.SoilParametersFromFile(np.zeros((2001, 1)), 20, 25, 0.015)
     assert s.rdry_set is True and s.columns()[:3] == [None, None, None]
+
+
+def test_bench_finds_its_committed_profile_numbers():
+    """bench.py reads roofline.traffic / roofline.valu from the committed rocprofv3 passes by kernel name: a kernel
+    rename or a profile refresh under another tag must not silently turn them into null."""
+    import importlib.util
+    import os
+    root = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    t = bench.measured_traffic("k_bands<float,0,true>")
+    assert t is not None and 3.0e8 < t < 4.5e8            # 372 MB algorithmic per 1M spectra
+    v = bench.measured_valu(10.9e-3)
+    assert 8e9 < v["wave_insts_per_launch"] < 1.0e10 and 0.5 < v["issue_frac"] < 0.8
+    assert bench.algorithmic_bytes(13, "float32") == 27 * 8 + 3 * 13 * 4
