@@ -1,0 +1,66 @@
+"""Occupancy guard (no GPU needed: hipcc cross-compiles): the register budgets the performance numbers rest on.
+
+The band kernel's speed depends on resident waves per SIMD (512 VGPRs / wave budget): 5 for the float32 kernels
+(<= 96 VGPRs, no scratch), 2 for the float64 ones (<= 256).  A change that silently pushes a kernel over the edge
+would only show up as a slower benchmark; this test makes it a failure on the build machine."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+SRC = os.path.join(ROOT, "spart-python_amd", "csrc", "spart_capi.hip")
+
+
+def _hipcc():
+    for c in ("/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if c and os.path.exists(c):
+            return c
+    return None
+
+
+@pytest.fixture(scope="module")
+def kernel_meta(tmp_path_factory):
+    cc = _hipcc()
+    if cc is None:
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("isa") / "capi.s"
+    subprocess.check_call([cc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-slp-vectorize", "-DSPART_FAST_MATH=1",
+                           "-S", "--cuda-device-only", "-o", str(out), SRC], stderr=subprocess.DEVNULL)
+    meta, cur = {}, None
+    for line in open(out):
+        m = re.match(r"\s+\.name:\s+(\S+)", line)
+        if m:
+            cur = m.group(1)
+            meta[cur] = {}
+            continue
+        m = re.match(r"\s+\.(vgpr_count|vgpr_spill_count|sgpr_spill_count|private_segment_fixed_size):\s+(\d+)", line)
+        if m and cur:
+            meta[cur][m.group(1)] = int(m.group(2))
+    return meta
+
+
+def _find(meta, fragment):
+    hits = [v for k, v in meta.items() if fragment in k and "vgpr_count" in v]
+    assert hits, fragment
+    return hits
+
+
+def test_float32_band_kernels_keep_five_waves_per_simd(kernel_meta):
+    for frag in ("k_bandsIfLi0ELb1E", "k_bandsIfLi1ELb1E", "k_bandsIfLi2ELb1E"):
+        for k in _find(kernel_meta, frag):
+            assert k["vgpr_count"] <= 96, (frag, k)
+            assert k["private_segment_fixed_size"] == 0 and k["vgpr_spill_count"] == 0, (frag, k)
+
+
+def test_float64_band_kernels_keep_two_waves_per_simd(kernel_meta):
+    for k in _find(kernel_meta, "k_bandsIdLi0ELb1E"):
+        assert k["vgpr_count"] <= 256, k
+        assert k["private_segment_fixed_size"] <= 64, k        # a handful of spilled values, not a spilled loop
+
+
+def test_sensor_kernel_fits_sixteen_waves(kernel_meta):
+    for k in _find(kernel_meta, "k_sensorI"):
+        assert k["vgpr_count"] <= 128 and k["private_segment_fixed_size"] == 0, k
