@@ -116,6 +116,11 @@ struct Workspace {
 // 256 CUs), so the per-chunk band sums stay <= 64 MB (fp32) whatever B is.  Small batches: at least
 // min(32, B/256) samples per workgroup so that the 17 table loads per lane are amortised while ~2000
 // workgroups remain.
+// the band kernels address a chunk's rows with a 32-bit byte offset per lane
+bool chunk_fits_32bit(int chunk, int pitch, size_t es) {
+  return (int64_t)chunk * (int64_t)pitch * (int64_t)es <= (int64_t)3900000000LL;
+}
+
 int pick_chunk(int64_t B) {
   static const int forced = [] { const char* e = std::getenv("SPART_CHUNK"); return e ? std::atoi(e) : 0; }();   // tuning knob
   if (forced > 0) return forced;
@@ -178,6 +183,7 @@ static int prospect_impl(spart_ctx* ctx, int64_t B, const double* const leaf[9],
   int chunk = pick_chunk(B);
   int64_t nchunk = (B + chunk - 1) / chunk;
   const T* tab = sizeof(T) == 4 ? (const T*)ctx->tabF : (const T*)ctx->tabD;
+  if (!chunk_fits_32bit(chunk, ctx->po, sizeof(T))) return fail(ctx, SPART_ERR_INVALID, "batch too large for one call");
   hipLaunchKernelGGL((k_prospect<T>), dim3(xcd_grid(nchunk)), dim3(TILE), 0, st, tab, (const T*)cst, B, chunk,
                      ctx->po, (T*)refl, (T*)tran, (T*)kchl);
   HIP_TRY(ctx, hipGetLastError());
@@ -196,6 +202,7 @@ static int bsm_impl(spart_ctx* ctx, int64_t B, const double* const soil[6], cons
   int chunk = pick_chunk(B);
   int64_t nchunk = (B + chunk - 1) / chunk;
   const T* tab = sizeof(T) == 4 ? (const T*)ctx->tabF : (const T*)ctx->tabD;
+  if (!chunk_fits_32bit(chunk, ctx->po, sizeof(T))) return fail(ctx, SPART_ERR_INVALID, "batch too large for one call");
   hipLaunchKernelGGL((k_bsm<T>), dim3(xcd_grid(nchunk)), dim3(TILE), 0, st, tab, (const T*)cst, B, chunk,
                      ctx->po, (const T*)rdry_in, (T*)refl, (T*)dry);
   HIP_TRY(ctx, hipGetLastError());
@@ -215,6 +222,7 @@ static int sailh_impl(spart_ctx* ctx, int64_t B, const void* rho, const void* ta
   if (rc) return rc;
   int chunk = pick_chunk(B);
   int64_t nchunk = (B + chunk - 1) / chunk;
+  if (!chunk_fits_32bit(chunk, ctx->pf, sizeof(T))) return fail(ctx, SPART_ERR_INVALID, "batch too large for one call");
   hipLaunchKernelGGL((k_sailh<T>), dim3((unsigned)(nchunk * NTILE_FULL)), dim3(TILE), 0, st, (const T*)cst, B, chunk,
                      ctx->pf, (const T*)rho, (const T*)tau, (const T*)rs, (T*)out4[0], (T*)out4[1], (T*)out4[2], (T*)out4[3]);
   HIP_TRY(ctx, hipGetLastError());
@@ -258,7 +266,7 @@ static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_
   }
   dim3 grid(xcd_grid(nchunk));
   T* bsum = (T*)(wsp + ws.bs_off);
-  if (mat && (int64_t)chunk * (int64_t)ctx->pf * (int64_t)sizeof(T) > (int64_t)3900000000LL)
+  if (mat && !chunk_fits_32bit(chunk, ctx->pf, sizeof(T)))
     return fail(ctx, SPART_ERR_INVALID, "batch too large for materialised spectra in one call (chunk %d rows x pitch %d)", chunk, ctx->pf);
   const bool full = !(opt && opt->prune_unused_bands);
   if (opt && opt->band_mean && !full)
