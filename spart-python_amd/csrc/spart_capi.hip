@@ -333,14 +333,24 @@ static int lut_impl(spart_ctx* ctx, int64_t B, int nb, const void* lut, int64_t 
   int64_t* pi = (int64_t*)((char*)pc + align_up((size_t)nslice * M * sizeof(T)));
   dim3 gprep((unsigned)((B + 255) / 256));
   dim3 grid((unsigned)((M + 255) / 256), (unsigned)nslice);
+  dim3 grid2((unsigned)((M + 511) / 512), (unsigned)nslice);       // float32: two observations per lane
+  const bool pk = sizeof(T) == 4 && (B + nslice - 1) / nslice < (int64_t)2000000000LL;
   if (nbp == 16) {
     hipLaunchKernelGGL((k_lut_prep<T, 16>), gprep, dim3(256), 0, st, (const T*)lut, (const T*)weights, nb, B, padded);
-    hipLaunchKernelGGL((k_lut_scan<T, 16>), grid, dim3(256), 0, st, (const T*)padded, (const T*)obs, (const T*)weights, nb,
-                       B, M, nslice, pc, pi);
+    if (pk)
+      hipLaunchKernelGGL((k_lut_scan2<16>), grid2, dim3(256), 0, st, (const float*)padded, (const float*)obs,
+                         (const float*)weights, nb, B, M, nslice, (float*)pc, pi);
+    else
+      hipLaunchKernelGGL((k_lut_scan<T, 16>), grid, dim3(256), 0, st, (const T*)padded, (const T*)obs, (const T*)weights,
+                         nb, B, M, nslice, pc, pi);
   } else {
     hipLaunchKernelGGL((k_lut_prep<T, 32>), gprep, dim3(256), 0, st, (const T*)lut, (const T*)weights, nb, B, padded);
-    hipLaunchKernelGGL((k_lut_scan<T, 32>), grid, dim3(256), 0, st, (const T*)padded, (const T*)obs, (const T*)weights, nb,
-                       B, M, nslice, pc, pi);
+    if (pk)
+      hipLaunchKernelGGL((k_lut_scan2<32>), grid2, dim3(256), 0, st, (const float*)padded, (const float*)obs,
+                         (const float*)weights, nb, B, M, nslice, (float*)pc, pi);
+    else
+      hipLaunchKernelGGL((k_lut_scan<T, 32>), grid, dim3(256), 0, st, (const T*)padded, (const T*)obs, (const T*)weights,
+                         nb, B, M, nslice, pc, pi);
   }
   HIP_TRY(ctx, hipGetLastError());
   hipLaunchKernelGGL((k_lut_reduce<T>), dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, (const T*)pc, (const int64_t*)pi,

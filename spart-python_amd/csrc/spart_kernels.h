@@ -601,6 +601,51 @@ __global__ __launch_bounds__(256) void k_lut_scan(const T* __restrict__ padded, 
   }
 }
 
+
+// float32 scan with TWO observations per lane: the accumulators of observations 2m and 2m+1 form one packed pair, so a
+// LUT row costs NBP-1 v_pk_fma_f32 (row value from an SGPR, broadcast to both halves; the observations' -2 w y in VGPR
+// pairs) instead of 2 (NBP-1) v_fma_f32 with an SGPR source -- a packed FMA issues in 2.29 ns against 2 x 1.85
+// (profiles/r1_ubench_pk_issue.txt, r1_ubench_valu_issue.txt).  The winning row is tracked as a 32-bit offset into
+// the slice.
+typedef float spart_f2 __attribute__((ext_vector_type(2)));
+template <int NBP>
+__global__ __launch_bounds__(256) void k_lut_scan2(const float* __restrict__ padded, const float* __restrict__ obs,
+                                                   const float* __restrict__ w, int nb, int64_t B, int64_t M, int nslice,
+                                                   float* __restrict__ part_cost, int64_t* __restrict__ part_idx) {
+  const int64_t m0 = 2 * ((int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+  const int slice = blockIdx.y;
+  const int64_t ma = m0 < M ? m0 : M - 1, mb = m0 + 1 < M ? m0 + 1 : M - 1;
+  spart_f2 yw[NBP - 1];
+#pragma unroll
+  for (int j = 0; j < NBP - 1; ++j) {
+    const float wj = (j < nb) ? -2.0f * (w ? w[j] : 1.0f) : 0.0f;
+    yw[j] = spart_f2{(j < nb) ? wj * obs[ma * nb + j] : 0.0f, (j < nb) ? wj * obs[mb * nb + j] : 0.0f};
+  }
+  const int64_t per = (B + nslice - 1) / nslice;
+  const int64_t b0 = per * slice;
+  const int64_t b1 = (b0 + per < B) ? b0 + per : B;
+  const int n = (int)(b1 > b0 ? b1 - b0 : 0);
+  float best_a = INFINITY, best_b = INFINITY;
+  int ia = -1, ib = -1;
+  const float* __restrict__ x = padded + b0 * NBP;     // wave-uniform, NBP-aligned rows -> wide scalar loads
+#pragma unroll 2
+  for (int r = 0; r < n; ++r, x += NBP) {
+    spart_f2 acc = spart_f2{x[NBP - 1], x[NBP - 1]};
+#pragma unroll
+    for (int j = 0; j < NBP - 1; ++j) acc = __builtin_elementwise_fma(spart_f2{x[j], x[j]}, yw[j], acc);
+    if (acc.x < best_a) { best_a = acc.x; ia = r; }
+    if (acc.y < best_b) { best_b = acc.y; ib = r; }
+  }
+  if (m0 < M) {
+    part_cost[(int64_t)slice * M + m0] = best_a;
+    part_idx[(int64_t)slice * M + m0] = ia < 0 ? -1 : b0 + ia;
+  }
+  if (m0 + 1 < M) {
+    part_cost[(int64_t)slice * M + m0 + 1] = best_b;
+    part_idx[(int64_t)slice * M + m0 + 1] = ib < 0 ? -1 : b0 + ib;
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_lut_reduce(const T* __restrict__ part_cost, const int64_t* __restrict__ part_idx,
                                                     const T* __restrict__ obs, const T* __restrict__ w, int nb, int64_t M,
