@@ -235,8 +235,13 @@ template <> struct SailJ<double> {
 };
 // J1 = L (tk - e1)/d with tk = e^-kL, e1 = e^-mL, d = (m - k) L, id = 1/d (unused on the Taylor side)
 template <typename T> SPART_HD T sail_j1_d(T L, T tk, T e1, T d, T id) {
-  if (Mx<T>::fabs(d) < SailJ<T>::THRESH) return L * tk * SailJ<T>::poly(d);
-  return L * (tk - e1) * id;
+  T v = L * (tk - e1) * id;              // (id is a finite dummy where |d| is small)
+  const bool small = Mx<T>::fabs(d) < SailJ<T>::THRESH;
+  if (SPART_WAVE_ANY(small)) {           // m within 0.06 / LAI of k or K: rare, issued only when some lane needs it
+    SPART_KEEP_BRANCH(d);
+    v = small ? L * tk * SailJ<T>::poly(d) : v;
+  }
+  return v;
 }
 // J2 = (1 - tk e1)/(k + m), kpm = k + m > 0, ikpm = 1/kpm; (k + m) L < THRESH selects L phi((k + m) L) -- rare, and
 // the Taylor side is only issued when some lane of the wave needs it
