@@ -303,7 +303,9 @@ static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_
     const int narr = 3 + (want_rsoil ? 1 : 0) + ((opt && opt->La) ? 1 : 0);
     const size_t lds = (size_t)narr * 64 * ctx->nb * sizeof(T);      // <= 5 * 64 * 64 * 8 = 160 KiB only for nb = 64 fp64
     if (lds > 64 * 1024) return fail(ctx, SPART_ERR_INVALID, "spart_run_batch: %d sensor bands need %zu B of LDS staging", ctx->nb, lds);
-    const int nwave = ctx->nb < 16 ? ctx->nb : 16;
+    // 4 waves (each walking every 4th band) per 64-sample workgroup: with one wave per band (13 for Sentinel-2) a
+    // CU holds a single workgroup and the kernel is 0.25 ms per 1M spectra slower (sweep 2..13: 2-4 equal)
+    const int nwave = ctx->nb < 4 ? ctx->nb : 4;
     hipLaunchKernelGGL((k_sensor<T>), dim3((unsigned)((B + 63) / 64)), dim3(64 * nwave), lds, st, stb, (const T*)G,
                        (const double*)atm, B, (T*)R_TOC, (T*)R_TOA, (T*)L_TOA, (const T*)(want_rsoil ? gs : nullptr),
                        (T*)(opt ? opt->rsoil : nullptr), (T*)(opt ? opt->La : nullptr));
