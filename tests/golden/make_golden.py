@@ -15,6 +15,8 @@ Files
   smac.npz       per sensor: angles, atm + the 9 AtmosphericOptics fields (smac.py:14)
   e2e.npz        full SPART(...).run() rows: defaults x 9 sensors, README/MODIS, PRO/S2B,
                  256 rows of the config-4 LHS (S2A), 64 rows config-5 LHS (S2B), 32 LHS rows MODIS/L7/S3A
+  edge.npz       128 rows of tools/edge_sweep.py's widened ranges with edge values (LAI 0 / 1e-4 / 10, dry soil, N = 1,
+                 zero pigments, exact hot spot, grazing angles, PRO leaves), Sentinel2A: P + R_TOC / R_TOA / L_TOA
 """
 import io
 import itertools
@@ -225,7 +227,21 @@ def gen_rdry():
     print("rdry", len(rows))
 
 
+def gen_edge():
+    import warnings
+    import edge_sweep                      # tools/edge_sweep.py: the generator of the widened-range rows
+    P = edge_sweep.draw(32768)[:128]
+    warnings.filterwarnings("ignore")
+    with np.errstate(all="ignore"), Pool(8) as pool:
+        res = pool.map(run_row, [(r, edge_sweep.SENSOR) for r in P], chunksize=4)
+    out = {"P": P, "sensor": np.array(edge_sweep.SENSOR)}
+    for j, k in enumerate(["R_TOC", "R_TOA", "L_TOA"]):
+        out[k] = np.array([r[j] for r in res])
+    np.savez_compressed(os.path.join(HERE, "edge.npz"), **out)
+    print("edge", P.shape, "non-finite reference entries:", int((~np.isfinite(out["R_TOC"])).sum()))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["prospect", "bsm", "sailh", "smac", "e2e", "rdry"]
+    which = sys.argv[1:] or ["prospect", "bsm", "sailh", "smac", "e2e", "rdry", "edge"]
     for w in which:
         globals()["gen_" + w]()

@@ -433,3 +433,23 @@ def test_row_pitch_dense_and_padded_agree(torch_mod):
         rb = dense.run(P, dtype, rdry=sb[1], materialize=("soil_refl",))
         for k in ("soil_refl", "R_TOC", "R_TOA", "L_TOA"):
             assert torch_mod.equal(ra[k], rb[k]), (dtype, k)
+
+
+def test_edge_rows_golden(golden, torch_mod):
+    """The widened-range / edge-value rows of tests/golden/edge.npz (real reference outputs) through the C ABI.  float64:
+    every row whose leaf has water or dry matter (without either, refl + tran = 1 exactly in the infrared and the
+    reference divides by zero); float32: rows whose reference reflectances are still physical (0 <= R_TOC <= 1)."""
+    from spart_amd import get_engine
+    g = golden["edge"]
+    P = g["P"]
+    eng = get_engine(str(g["sensor"]), 0)
+    Pd = torch_mod.as_tensor(P.T.copy(), device="cuda:0")
+    o64, o32 = eng.run(Pd, "float64"), eng.run(Pd, "float32")
+    keep = (P[:, 1] + P[:, 2]) > 0
+    assert keep.sum() > 100
+    for k, floor, tol in (("R_TOC", 1e-6, 1e-6), ("R_TOA", 1e-2, 2e-6), ("L_TOA", 1e-2, 2e-6)):
+        assert rel_err(o64[k].cpu().numpy()[keep], g[k][keep], floor) < tol, k
+    phys = keep & np.all((g["R_TOC"] >= 0) & (g["R_TOC"] <= 1), axis=1)
+    assert phys.sum() > 60
+    for k in ("R_TOC", "R_TOA", "L_TOA"):
+        assert rel_err(o32[k].cpu().numpy()[phys], g[k][phys], 1e-3) < 1e-4, k

@@ -82,6 +82,18 @@ def test_full_chain(oracle, tables, golden):
         assert rel_err(got, g[name + "/probes"], 0.1) < 1e-6, name   # abs 1e-7: the reference E1 quadrature noise
 
 
+def test_edge_rows(oracle, tables, golden):
+    """128 rows from widened parameter ranges with edge values (LAI 0 / 1e-4 / 10, dry soil, N = 1, zero pigments, exact
+    hot spot, grazing angles, PRO leaves) run through the real reference: the oracle follows it everywhere, including
+    where its outputs have left the physical range (R_TOC down to -1e2)."""
+    g = golden["edge"]
+    with np.errstate(all="ignore"):
+        o = oracle.spart_run(g["P"], str(g["sensor"]), tables, pso="gl")
+    assert rel_err(o["R_TOC"], g["R_TOC"], 1e-6) < 1e-6
+    for k in ("R_TOA", "L_TOA"):                       # float32 SMAC coefficients in the Sentinel-2 pickle: 1e-8 absolute
+        assert rel_err(o[k], g[k], 1e-2) < 2e-6, k
+
+
 def test_known_answer_pins(oracle, tables):
     """SURVEY.md §8(a) pins captured from the reference (defaults, Sentinel2A, DOY 100)."""
     from spart_amd_workloads import default_row

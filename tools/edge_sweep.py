@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.join(ROOT, "spart-python_amd"))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
+N = int(sys.argv[1]) if (__name__ == "__main__" and len(sys.argv) > 1) else 32768
 SENSOR = "Sentinel2A-MSI"
 
 
