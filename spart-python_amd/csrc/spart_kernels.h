@@ -190,15 +190,26 @@ void k_bands(const T* __restrict__ tab, const T* __restrict__ cst,
     T refl, tran, absb, K;
     leaf_band<T>(tb, c[C_CAB], c[C_CCA], c[C_CDM], c[C_CW], c[C_CS], c[C_CANT], c[C_CBC], c[C_PROT], c[C_NM1], refl,
                  tran, absb, K);
-    T rdry = (MAT == 2) ? mat.rdry_in[s * mat.po + ti] : soil_dry<T>(tb, c[C_F1], c[C_F2], c[C_F3]);
-    T fm[7] = {c[C_FM0], c[C_FM1], c[C_FM2], c[C_FM3], c[C_FM4], c[C_FM5], c[C_FM6]};
-    T rwet;
-    soil_band<T>(tb, rdry, c[C_WET], fm, c[C_FMSUM], c[C_FILM2L], rwet);
     T rho = refl, tau = tran, ab = absb;
     if (tile == NTILE - 1) {                           // block-uniform: only the last tile holds the thermal evaluation
       rho = thermal ? c[C_RHO_TH] : refl;              // SPART.py:463-466
       tau = thermal ? c[C_TAU_TH] : tran;
       ab = thermal ? (T(1) - c[C_RHO_TH] - c[C_TAU_TH]) : absb;
+    }
+    // materialised spectra are stored as soon as they exist (leaf, then soil, then canopy) so that the store stream
+    // is spread over the iteration instead of arriving as one burst of 9-11 stores at its end
+    if (MAT && active) {
+      if (mat.leaf_refl) store_row(mat.leaf_refl, off_f, rho);
+      if (mat.leaf_tran) store_row(mat.leaf_tran, off_f, tau);
+      if (!thermal && mat.leaf_kchl) store_row(mat.leaf_kchl, off_o, (K > T(0)) ? divx(c[C_CAB] * tb.kab, K) : T(0));  // prospect_5d.py:197-198
+    }
+    T rdry = (MAT == 2) ? mat.rdry_in[s * mat.po + ti] : soil_dry<T>(tb, c[C_F1], c[C_F2], c[C_F3]);
+    T fm[7] = {c[C_FM0], c[C_FM1], c[C_FM2], c[C_FM3], c[C_FM4], c[C_FM5], c[C_FM6]};
+    T rwet;
+    soil_band<T>(tb, rdry, c[C_WET], fm, c[C_FMSUM], c[C_FILM2L], rwet);
+    if (MAT && active) {
+      if (mat.soil_refl) store_row(mat.soil_refl, off_f, rwet);
+      if (!thermal && mat.soil_dry) store_row(mat.soil_dry, off_o, rdry);
     }
     const CanopyPar<T> cp = load_canopy(c);
     T rso, rdo, rsd, rdd;
@@ -212,17 +223,10 @@ void k_bands(const T* __restrict__ tab, const T* __restrict__ cst,
     }
     if (MAT) {
       if (active) {
-        if (mat.leaf_refl) store_row(mat.leaf_refl, off_f, rho);
-        if (mat.leaf_tran) store_row(mat.leaf_tran, off_f, tau);
-        if (mat.soil_refl) store_row(mat.soil_refl, off_f, rwet);
         if (mat.rso) store_row(mat.rso, off_f, rso);
         if (mat.rdo) store_row(mat.rdo, off_f, rdo);
         if (mat.rsd) store_row(mat.rsd, off_f, rsd);
         if (mat.rdd) store_row(mat.rdd, off_f, rdd);
-        if (!thermal) {
-          if (mat.leaf_kchl) store_row(mat.leaf_kchl, off_o, (K > T(0)) ? divx(c[C_CAB] * tb.kab, K) : T(0));  // prospect_5d.py:197-198
-          if (mat.soil_dry) store_row(mat.soil_dry, off_o, rdry);
-        }
         if (mat.gsoil && slot >= 0) (mat.gsoil + s * nslot)[slot] = rwet;
       }
       // thermal padding (SPART.py:427-470): the wave that holds the thermal evaluation (band 2001) copies it over
