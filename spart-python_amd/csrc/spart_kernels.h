@@ -203,6 +203,10 @@ void k_bands(const T* __restrict__ tab, const T* __restrict__ cst,
       if (mat.leaf_tran) store_row(mat.leaf_tran, off_f, tau);
       if (!thermal && mat.leaf_kchl) store_row(mat.leaf_kchl, off_o, (K > T(0)) ? divx(c[C_CAB] * tb.kab, K) : T(0));  // prospect_5d.py:197-198
     }
+    // order: leaf -> canopy solve for the leaf alone -> soil -> coupling with the soil background.  The soil model
+    // sits between the two canopy parts because that schedule measured fastest (interleaved A/B of four orders).
+    const CanopyPar<T> cp = load_canopy(c);
+    const CanopyCore<T> core = canopy_core<T>(cp, rho, tau, ab);
     T rdry = (MAT == 2) ? mat.rdry_in[s * mat.po + ti] : soil_dry<T>(tb, c[C_F1], c[C_F2], c[C_F3]);
     T fm[7] = {c[C_FM0], c[C_FM1], c[C_FM2], c[C_FM3], c[C_FM4], c[C_FM5], c[C_FM6]};
     T rwet;
@@ -211,9 +215,8 @@ void k_bands(const T* __restrict__ tab, const T* __restrict__ cst,
       if (mat.soil_refl) store_row(mat.soil_refl, off_f, rwet);
       if (!thermal && mat.soil_dry) store_row(mat.soil_dry, off_o, rdry);
     }
-    const CanopyPar<T> cp = load_canopy(c);
     T rso, rdo, rsd, rdd;
-    canopy_band<T>(cp, rho, tau, ab, rwet, rso, rdo, rsd, rdd);
+    canopy_soil<T>(cp, core, rwet, rso, rdo, rsd, rdd);
     if (FULL) {
       sum_so += rso; sum_do += rdo; sum_sd += rsd; sum_dd += rdd;
     }
@@ -278,16 +281,17 @@ __global__ __launch_bounds__(256) void k_bands_pruned(const T* __restrict__ tab,
   T refl, tran, absb, K;
   leaf_band<T>(tb, c[C_CAB], c[C_CCA], c[C_CDM], c[C_CW], c[C_CS], c[C_CANT], c[C_CBC], c[C_PROT], c[C_NM1], refl,
                tran, absb, K);
+  T rho = thermal ? c[C_RHO_TH] : refl;
+  T tau = thermal ? c[C_TAU_TH] : tran;
+  T ab = thermal ? (T(1) - c[C_RHO_TH] - c[C_TAU_TH]) : absb;
+  const CanopyPar<T> cp = load_canopy(c);                      // (same order of the parts as in k_bands)
+  const CanopyCore<T> core = canopy_core<T>(cp, rho, tau, ab);
   T rdry = soil_dry<T>(tb, c[C_F1], c[C_F2], c[C_F3]);
   T fm[7] = {c[C_FM0], c[C_FM1], c[C_FM2], c[C_FM3], c[C_FM4], c[C_FM5], c[C_FM6]};
   T rwet;
   soil_band<T>(tb, rdry, c[C_WET], fm, c[C_FMSUM], c[C_FILM2L], rwet);
-  T rho = thermal ? c[C_RHO_TH] : refl;
-  T tau = thermal ? c[C_TAU_TH] : tran;
-  T ab = thermal ? (T(1) - c[C_RHO_TH] - c[C_TAU_TH]) : absb;
-  const CanopyPar<T> cp = load_canopy(c);
   T rso, rdo, rsd, rdd;
-  canopy_band<T>(cp, rho, tau, ab, rwet, rso, rdo, rsd, rdd);
+  canopy_soil<T>(cp, core, rwet, rso, rdo, rsd, rdd);
   T* g = G + i * 4;
   g[0] = rso; g[1] = rdo; g[2] = rsd; g[3] = rdd;
 }

@@ -454,8 +454,14 @@ template <typename T> struct CanopyPar {
   T sob, sof, hbf, ks, ko, lai, lai2, tss, too, Z, hot, pso2w;   // hbf = bf/2, lai2 = LAI log2(e)
 };
 
+// The solve in two parts: everything that depends on the leaf only (canopy_core), and the coupling with the soil
+// background (canopy_soil, :222-233).  canopy_band = both.
+template <typename T> struct CanopyCore {
+  T rho_so, rho_dd, tau_dd, tau_sd, tau_do, rho_sd, rho_do;
+};
+
 template <typename T>
-SPART_HD void canopy_band(const CanopyPar<T>& c, T rho, T tau, T absb, T rs, T& rso, T& rdo, T& rsd, T& rdd) {
+SPART_HD CanopyCore<T> canopy_core(const CanopyPar<T>& c, T rho, T tau, T absb) {
   // scattering coefficients (:142-148).  With sdb/sdf = (k +- bf)/2, ddb/ddf = (1 +- bf)/2, dob/dof = (K +- bf)/2
   // (:100-105) they are P, k P, K P plus/minus Mn, where P = (rho + tau)/2 and Mn = bf (rho - tau)/2:
   //   sigb = P + Mn, sigf = P - Mn, sb/sf = k P +- Mn, vb/vf = K P +- Mn
@@ -513,6 +519,13 @@ SPART_HD void canopy_band(const CanopyPar<T>& c, T rho, T tau, T absb, T rs, T& 
   T T2 = -(Qoo * rho_sd + Poo * tau_sd) * rinf;                                      // :213
   T rho_sod = (T1 + T2) * i2;                                                        // :214
   T rho_so = rho_sod + w * c.hot;                                 // :216-217
+  return CanopyCore<T>{rho_so, rho_dd, tau_dd, tau_sd, tau_do, rho_sd, rho_do};
+}
+
+template <typename T>
+SPART_HD void canopy_soil(const CanopyPar<T>& c, const CanopyCore<T>& k, T rs, T& rso, T& rdo, T& rsd, T& rdd) {
+  const T rho_so = k.rho_so, rho_dd = k.rho_dd, tau_dd = k.tau_dd, tau_sd = k.tau_sd, tau_do = k.tau_do, rho_sd = k.rho_sd,
+          rho_do = k.rho_do;
   T g = rs * Mx<T>::rcp(T(1) - rs * rho_dd);                      // rs / (1 - rs rho_dd)   (:222)
   T h = g * tau_dd;
   T tst = c.tss + tau_sd;
@@ -520,6 +533,12 @@ SPART_HD void canopy_band(const CanopyPar<T>& c, T rho, T tau, T absb, T rs, T& 
   rdo = rho_do + (c.too + tau_do) * h;                            // :231
   rsd = rho_sd + tst * h;                                         // :232
   rdd = rho_dd + tau_dd * h;                                      // :233
+}
+
+template <typename T>
+SPART_HD void canopy_band(const CanopyPar<T>& c, T rho, T tau, T absb, T rs, T& rso, T& rdo, T& rsd, T& rdd) {
+  const CanopyCore<T> k = canopy_core<T>(c, rho, tau, absb);
+  canopy_soil<T>(c, k, rs, rso, rdo, rsd, rdd);
 }
 
 // ------------------------------------------------------------------------------------------
