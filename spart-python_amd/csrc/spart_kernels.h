@@ -184,12 +184,28 @@ void k_bands(const T* __restrict__ tab, const T* __restrict__ cst,
   __syncthreads();                                     // the previous sub-chunk has been consumed by every wave
   for (int i = threadIdx.x; i < nsub * NCONST; i += TILE) lds_c[i] = cst[sb * NCONST + i];
   __syncthreads();
+  // the nine leaf constants are read one sample ahead (they are the first thing an iteration needs: without the
+  // prefetch every iteration starts by waiting for its own LDS reads).  Not in the materialising variants: there the
+  // nine registers cost a wave of occupancy (109 VGPRs).
+  constexpr bool AHEAD = MAT == 0 && sizeof(T) == 4;   // (float64: the 18 registers are missed elsewhere, +0.4 %)
+  T lc[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) lc[i] = lds_c[i];
   for (int si = 0; si < nsub; ++si) {
     const int64_t s = sb + si;
     const T* c = lds_c + si * NCONST;                  // uniform LDS address -> broadcast ds_read into VGPRs
     T refl, tran, absb, K;
-    leaf_band<T>(tb, c[C_CAB], c[C_CCA], c[C_CDM], c[C_CW], c[C_CS], c[C_CANT], c[C_CBC], c[C_PROT], c[C_NM1], refl,
-                 tran, absb, K);
+    static_assert(C_CAB == 0 && C_NM1 == 8, "lc[] = constants 0..8 in leaf_band's argument order");
+    if (!AHEAD) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) lc[i] = c[i];
+    }
+    leaf_band<T>(tb, lc[0], lc[1], lc[2], lc[3], lc[4], lc[5], lc[6], lc[7], lc[8], refl, tran, absb, K);
+    if (AHEAD) {
+      const T* cn = lds_c + ((si + 1 < nsub) ? si + 1 : si) * NCONST;   // next sample's leaf constants, in flight early
+#pragma unroll
+      for (int i = 0; i < 9; ++i) lc[i] = cn[i];
+    }
     T rho = refl, tau = tran, ab = absb;
     if (tile == NTILE - 1) {                           // block-uniform: only the last tile holds the thermal evaluation
       rho = thermal ? c[C_RHO_TH] : refl;              // SPART.py:463-466
