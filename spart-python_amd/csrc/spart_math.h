@@ -572,21 +572,45 @@ SPART_HD double lidf_dcum_newton(double a, double b, double theta_deg) {
   if (!(::fabs(a) + ::fabs(b) < 0.95)) return lidf_dcum(a, b, theta_deg);
   const double rd = PI / 180.0;
   const double theta2 = 2.0 * rd * theta_deg;
-  // start from one fixed-point step x1 = theta2 + y(theta2) (error <~ 0.05), then Newton: 0.05 -> 1e-3 -> 1e-6 ->
-  // 1e-12; the loop leaves as soon as a step is below 1e-9 (the next iterate is then exact to ~1e-17, far inside
-  // the ~1e-8 of the reference's own stopping rule)
-  double sn, cs;
-  ::sincos(theta2, &sn, &cs);
-  double x = theta2 + sn * (a + b * cs);
+  // Unknown y = x - theta2 (|y| <= |a| + |b|/2 < 1): sin x, cos x come from the angle-addition formulas with
+  // (sin, cos)(theta2) -- one sincos per boundary, a compile-time constant where the boundary loop is unrolled --
+  // and the Taylor polynomials of sin y, cos y (to y^19 / y^18: 3e-17 at |y| = 1), instead of a library sincos of
+  // x in every Newton step.  Start: one fixed-point step y0 = sin theta2 (a + b cos theta2) (error <~ 0.05), then
+  // 0.05 -> 1e-3 -> 1e-6 -> 1e-12; the loop leaves as soon as a step is below 1e-9 (the next iterate is then exact
+  // to ~1e-17, far inside the ~1e-8 of the reference's own stopping rule).
+  double s2, c2;
+  ::sincos(theta2, &s2, &c2);
+  double y = s2 * (a + b * c2);
   for (int it = 0; it < 12; ++it) {
-    ::sincos(x, &sn, &cs);
-    double f = x - theta2 - sn * (a + b * cs);
-    double fp = 1.0 - a * cs - b * (2.0 * cs * cs - 1.0);
-    double d = f / fp;
-    x -= d;
+    const double y2 = y * y;
+    double ps = -1.0 / 121645100408832000.0;            // sin y / y:  ... - y^18/19!
+    ps = ps * y2 + 1.0 / 355687428096000.0;
+    ps = ps * y2 - 1.0 / 1307674368000.0;
+    ps = ps * y2 + 1.0 / 6227020800.0;
+    ps = ps * y2 - 1.0 / 39916800.0;
+    ps = ps * y2 + 1.0 / 362880.0;
+    ps = ps * y2 - 1.0 / 5040.0;
+    ps = ps * y2 + 1.0 / 120.0;
+    ps = ps * y2 - 1.0 / 6.0;
+    ps = ps * y2 + 1.0;
+    double pc = 1.0 / 6402373705728000.0;                // cos y:  ... + y^18/18!
+    pc = pc * y2 - 1.0 / 20922789888000.0;
+    pc = pc * y2 + 1.0 / 87178291200.0;
+    pc = pc * y2 - 1.0 / 479001600.0;
+    pc = pc * y2 + 1.0 / 3628800.0;
+    pc = pc * y2 - 1.0 / 40320.0;
+    pc = pc * y2 + 1.0 / 720.0;
+    pc = pc * y2 - 1.0 / 24.0;
+    pc = pc * y2 + 0.5;
+    const double sy = y * ps, cy = 1.0 - y2 * pc;
+    const double sn = s2 * cy + c2 * sy, cs = c2 * cy - s2 * sy;   // sin x, cos x
+    const double f = y - sn * (a + b * cs);
+    const double fp = 1.0 - a * cs - b * (2.0 * cs * cs - 1.0);
+    const double d = f / fp;
+    y -= d;
     if (::fabs(d) < 1e-9) break;
   }
-  return (2.0 * (x - theta2) + theta2) / PI;
+  return (2.0 * y + theta2) / PI;
 }
 
 // F(theta_i) nodes: 10..80 step 10, 82..88 step 2, then F = 1   (sailh.py:388-394)
