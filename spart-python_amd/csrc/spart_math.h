@@ -568,18 +568,21 @@ SPART_HD double lidf_dcum(double a, double b, double theta_deg) {
 // quadratic convergence).  The reference stops its linear iteration at |dx| <= 1e-8, i.e. its F carries
 // an error of up to ~5e-8; the root differs from it by that much.  Used by the float32 path only
 // (tolerance 1e-4); |a| + |b| >= 0.95 (derivative may vanish) falls back to the literal iteration.
-SPART_HD double lidf_dcum_newton(double a, double b, double theta_deg) {
+SPART_HD double lidf_theta(int i);
+SPART_HD double lidf_sin_2theta(int i);
+SPART_HD double lidf_cos_2theta(int i);
+SPART_HD double lidf_dcum_newton(double a, double b, int i) {
+  const double theta_deg = lidf_theta(i);
   if (!(::fabs(a) + ::fabs(b) < 0.95)) return lidf_dcum(a, b, theta_deg);
   const double rd = PI / 180.0;
   const double theta2 = 2.0 * rd * theta_deg;
   // Unknown y = x - theta2 (|y| <= |a| + |b|/2 < 1): sin x, cos x come from the angle-addition formulas with
-  // (sin, cos)(theta2) -- one sincos per boundary, a compile-time constant where the boundary loop is unrolled --
+  // (sin, cos)(theta2) -- tabulated constants --
   // and the Taylor polynomials of sin y, cos y (to y^19 / y^18: 3e-17 at |y| = 1), instead of a library sincos of
   // x in every Newton step.  Start: one fixed-point step y0 = sin theta2 (a + b cos theta2) (error <~ 0.05), then
   // 0.05 -> 1e-3 -> 1e-6 -> 1e-12; the loop leaves as soon as a step is below 1e-9 (the next iterate is then exact
   // to ~1e-17, far inside the ~1e-8 of the reference's own stopping rule).
-  double s2, c2;
-  ::sincos(theta2, &s2, &c2);
+  const double s2 = lidf_sin_2theta(i), c2 = lidf_cos_2theta(i);
   double y = s2 * (a + b * c2);
   for (int it = 0; it < 12; ++it) {
     const double y2 = y * y;
@@ -617,6 +620,26 @@ SPART_HD double lidf_dcum_newton(double a, double b, double theta_deg) {
 SPART_HD double lidf_theta(int i) { return (i < 8) ? 10.0 * (i + 1) : 80.0 + 2.0 * (i - 7); }
 // litab: 5,15,...,75,81,83,...,89                                  (sailh.py:49)
 SPART_HD double lidf_litab(int i) { return (i < 8) ? 5.0 + 10.0 * i : 81.0 + 2.0 * (i - 8); }
+
+// sin / cos of the 13 class-centre inclinations litab(i) and of twice the 12 class boundaries theta(i): constants of
+// the model (sailh.py:49, 388-394), tabulated (math.sin / math.cos of the same double arguments) so that no sample
+// pays for 38 library calls on them
+SPART_HD double lidf_sin_litab(int i) {
+  static constexpr double t[NLINCL] = {0.08715574274765817, 0.25881904510252074, 0.42261826174069944, 0.573576436351046, 0.7071067811865475, 0.8191520442889918, 0.9063077870366499, 0.9659258262890683, 0.9876883405951378, 0.992546151641322, 0.9961946980917455, 0.9986295347545738, 0.9998476951563913};
+  return t[i];
+}
+SPART_HD double lidf_cos_litab(int i) {
+  static constexpr double t[NLINCL] = {0.9961946980917455, 0.9659258262890683, 0.9063077870366499, 0.8191520442889918, 0.7071067811865476, 0.5735764363510462, 0.42261826174069944, 0.25881904510252074, 0.15643446504023092, 0.12186934340514749, 0.08715574274765814, 0.052335956242943966, 0.0174524064372836};
+  return t[i];
+}
+SPART_HD double lidf_sin_2theta(int i) {
+  static constexpr double t[NLINCL - 1] = {0.3420201433256687, 0.6427876096865393, 0.8660254037844386, 0.984807753012208, 0.984807753012208, 0.8660254037844387, 0.6427876096865395, 0.3420201433256689, 0.2756373558169992, 0.20791169081775931, 0.13917310096006533, 0.06975647374412552};
+  return t[i];
+}
+SPART_HD double lidf_cos_2theta(int i) {
+  static constexpr double t[NLINCL - 1] = {0.9396926207859084, 0.766044443118978, 0.5000000000000001, 0.17364817766693041, -0.1736481776669303, -0.4999999999999998, -0.7660444431189779, -0.9396926207859083, -0.9612616959383189, -0.9781476007338057, -0.9902680687415704, -0.9975640502598242};
+  return t[i];
+}
 
 // lidf[13] = diff of the cumulative distribution (sailh.py:386-398)
 SPART_HD void leaf_angles(double a, double b, double lidf[NLINCL]) {
@@ -808,14 +831,13 @@ SPART_HD void sample_prelude(const double* p /*[27]*/, double rho_th, double tau
   double dso = ::sqrt(tan_tts * tan_tts + tan_tto * tan_tto - 2.0 * tan_tts * tan_tto * cos_psi);  // :78
   double ks = 0, ko = 0, bf = 0, sob = 0, sof = 0, Fprev = 0;
   for (int i = 0; i < NLINCL; ++i) {
-    double F = (i < NLINCL - 1) ? (FAST ? lidf_dcum_newton(LIDFa, LIDFb, lidf_theta(i))
+    double F = (i < NLINCL - 1) ? (FAST ? lidf_dcum_newton(LIDFa, LIDFb, i)
                                         : lidf_dcum(LIDFa, LIDFb, lidf_theta(i)))
                                 : 1.0;
     double li = F - Fprev;
     Fprev = F;
     lidf_out[i] = li;
-    double tl = lidf_litab(i) * d2r;
-    double sl = ::sin(tl), cl = ::cos(tl);
+    double sl = lidf_sin_litab(i), cl = lidf_cos_litab(i);   // sin / cos of litab(i), sailh.py:81
     double chi_s, chi_o, frho, ftau;
     volscatt1(sin_tts, cos_tts, sin_tto, cos_tto, psi_rad, sin_psi, cos_psi, sl, cl, chi_s, chi_o, frho, ftau);  // :81-83
     ks += chi_s / cos_tts * li;                                                               // :85, 93
