@@ -20,7 +20,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "spart-python_amd"))
 
-PROFILE_TAG = "r1_i"      # profiles/<tag>_traffic.json, <tag>_valu.json: the committed rocprofv3 PMC passes of this build
+PROFILE_TAG = "r1_j"      # profiles/<tag>_traffic.json, <tag>_valu.json: the committed rocprofv3 PMC passes of this build
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_VALU_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector
 
