@@ -20,7 +20,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "spart-python_amd"))
 
-PROFILE_TAG = "r1_j"      # profiles/<tag>_traffic.json, <tag>_valu.json: the committed rocprofv3 PMC passes of this build
+PROFILE_TAG = "r1_k"      # profiles/<tag>_traffic.json, <tag>_valu.json: the committed rocprofv3 PMC passes of this build
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_VALU_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector
 
@@ -214,8 +214,8 @@ def main():
                        "input_dtype": "f64", "finite": ok},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic("k_bands<float,0,true>") if std else None,
-                         "kernel": "k_bands<float,0,true>" if args.dtype == "float32" else "k_bands<double,0,true>",
+                         "traffic": measured_traffic("k_bands<float,0,1>") if std else None,
+                         "kernel": "k_bands<float,0,1>" if args.dtype == "float32" else "k_bands<double,0,1>",
                          "kernel_ms": kern_s * 1e3, "algorithmic_bytes_per_spectrum": algorithmic_bytes(nb, args.dtype),
                          "note": "fused path is VALU/transcendental bound by design (SURVEY.md §8d); HBM fraction is "
                                  "reported because the metric asks for it",

@@ -277,11 +277,15 @@ static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_
 #define SPART_LAUNCH_BANDS(M, F)                                                                                 \
   hipLaunchKernelGGL((k_bands<T, M, F>), grid, dim3(TILE), 0, st, tab, (const T*)cst, (const int*)ctx->need_slot, \
                      ctx->nslot, G, B, chunk, mp, bsum)
-  if (mat && mp.rdry_in && full) SPART_LAUNCH_BANDS(2, true);
-  else if (mat && mp.rdry_in) SPART_LAUNCH_BANDS(2, false);
-  else if (mat && full) SPART_LAUNCH_BANDS(1, true);
-  else if (mat) SPART_LAUNCH_BANDS(1, false);
-  else if (full) SPART_LAUNCH_BANDS(0, true);
+  const bool four = opt && opt->band_mean;     // the four band sums are only kept apart when their means are asked for
+  if (mat && mp.rdry_in && full && four) SPART_LAUNCH_BANDS(2, 2);
+  else if (mat && mp.rdry_in && full) SPART_LAUNCH_BANDS(2, 1);
+  else if (mat && mp.rdry_in) SPART_LAUNCH_BANDS(2, 0);
+  else if (mat && full && four) SPART_LAUNCH_BANDS(1, 2);
+  else if (mat && full) SPART_LAUNCH_BANDS(1, 1);
+  else if (mat) SPART_LAUNCH_BANDS(1, 0);
+  else if (full && four) SPART_LAUNCH_BANDS(0, 2);
+  else if (full) SPART_LAUNCH_BANDS(0, 1);
   else {   // columns only, pruning allowed: evaluate just the sensor's bands
     int64_t n = B * ctx->nslot;
     hipLaunchKernelGGL((k_bands_pruned<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, tab, (const T*)cst,

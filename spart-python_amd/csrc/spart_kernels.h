@@ -127,19 +127,19 @@ template <typename T> struct MatPtrs {
 // grid.x = nchunk * NTILE (tile fastest), block = 256.
 // G receives rso, rdo, rsd, rdd at the bands the sensor needs: (B, nslot, 4).
 //
-// FULL = true (the default mode of spart_run_batch): every one of the 2002 band evaluations of every
-// sample is observable -- each lane accumulates its band's four canopy reflectances over the chunk and
-// writes the sums to bandsum[chunk][2048][4] (reduced to batch-mean spectra by k_bandmean on request).
-// Without that the compiler legally sinks most of the soil / canopy arithmetic into the
-// `slot >= 0` store and skips it for the waves that hold no sensor band; that behaviour is the explicit
-// opt-in FULL = false ("prune_unused_bands").
+// FULL >= 1 (the default mode of spart_run_batch): every one of the 2002 band evaluations of every sample is
+// observable -- each lane accumulates its band's canopy reflectances over the chunk and stores the sum: FULL = 1 one
+// value per lane (rso + rdo + rsd + rdd: bandsum[chunk][2048], 8 KB per chunk), FULL = 2 the four sums separately
+// (bandsum[chunk][2048][4], reduced to batch-mean spectra by k_bandmean; chosen when band_mean is requested).
+// Without that the compiler legally sinks most of the soil / canopy arithmetic into the `slot >= 0` store and skips
+// it for the waves that hold no sensor band; that behaviour is the explicit opt-in FULL = 0 ("prune_unused_bands").
 // MAT: 0 = sensor columns only; 1 = also store the requested full spectra; 2 = 1 + per-sample dry-soil spectra are
 // READ (rdry_in).  The read is its own variant because a global load inside the sample loop makes the compiler wait
 // for vmcnt(0) -- i.e. for every outstanding store of the previous sample -- once per sample, which serialises the
 // store stream with the arithmetic.
 // fp64: left alone hipcc takes 262 VGPRs = ONE wave per SIMD; asking for two workgroups per CU (256 VGPRs, 7 spilled)
 // makes the fp64 mode 24 % faster (50.7 -> 38.6 ms per 1M spectra); three (168 VGPRs, 96 spilled) is 2.7x slower.
-template <typename T, int MAT, bool FULL>
+template <typename T, int MAT, int FULL>
 __global__ __launch_bounds__(TILE, (sizeof(T) == 8 ? 2 : 1))
 void k_bands(const T* __restrict__ tab, const T* __restrict__ cst,
                                                 const int* __restrict__ need_slot, int nslot, T* __restrict__ G,
@@ -233,8 +233,10 @@ void k_bands(const T* __restrict__ tab, const T* __restrict__ cst,
     }
     T rso, rdo, rsd, rdd;
     canopy_soil<T>(cp, core, rwet, rso, rdo, rsd, rdd);
-    if (FULL) {
+    if (FULL == 2) {
       sum_so += rso; sum_do += rdo; sum_sd += rsd; sum_dd += rdd;
+    } else if (FULL == 1) {
+      sum_so += (rso + rdo) + (rsd + rdd);
     }
     if (slot >= 0) {
       T* g = G + (s * nslot + slot) * 4;
@@ -272,9 +274,11 @@ void k_bands(const T* __restrict__ tab, const T* __restrict__ cst,
     }
   }
   }
-  if (FULL) {
+  if (FULL == 2) {
     T* bs = bandsum + (ck * (NTILE * TILE) + band) * 4;
     bs[0] = sum_so; bs[1] = sum_do; bs[2] = sum_sd; bs[3] = sum_dd;
+  } else if (FULL == 1) {
+    bandsum[ck * (NTILE * TILE) + band] = sum_so;
   }
 }
 

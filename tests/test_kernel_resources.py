@@ -49,14 +49,14 @@ def _find(meta, fragment):
 
 
 def test_float32_band_kernels_keep_five_waves_per_simd(kernel_meta):
-    for frag in ("k_bandsIfLi0ELb1E", "k_bandsIfLi1ELb1E", "k_bandsIfLi2ELb1E"):
+    for frag in ("k_bandsIfLi0ELi1E", "k_bandsIfLi1ELi1E", "k_bandsIfLi2ELi1E"):
         for k in _find(kernel_meta, frag):
             assert k["vgpr_count"] <= 96, (frag, k)
             assert k["private_segment_fixed_size"] == 0 and k["vgpr_spill_count"] == 0, (frag, k)
 
 
 def test_float64_band_kernels_keep_two_waves_per_simd(kernel_meta):
-    for k in _find(kernel_meta, "k_bandsIdLi0ELb1E"):
+    for k in _find(kernel_meta, "k_bandsIdLi0ELi1E"):
         assert k["vgpr_count"] <= 256, k
         assert k["private_segment_fixed_size"] <= 64, k        # a handful of spilled values, not a spilled loop
 
