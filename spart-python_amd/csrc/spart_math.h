@@ -892,9 +892,11 @@ SPART_HD void sample_prelude(const double* p /*[27]*/, double rho_th, double tau
   atm[A_LOGO3M] = ::log(p[23] * atm[A_M]);
   atm[A_LOGH2OM] = ::log(p[24] * atm[A_M]);
   double b = 2.0 * PI * p[26] / 365.0;
-  double corr = 1.00011 + 0.034221 * ::cos(b) + 0.00128 * ::sin(b) + 0.000719 * ::cos(2.0 * b) +
-                0.000077 * ::sin(2.0 * b);
-  atm[A_LAF] = corr * ::cos(tts * PI / 180.0) / PI;
+  double sb, cb;
+  ::sincos(b, &sb, &cb);                                    // cos 2b, sin 2b by the double-angle formulas; cos(tts) = us:
+  double corr = 1.00011 + 0.034221 * cb + 0.00128 * sb + 0.000719 * (cb * cb - sb * sb) +   // three library calls less,
+                0.000077 * (2.0 * sb * cb);                                                 // 1e-16 from the literal form
+  atm[A_LAF] = corr * us / PI;                              // SPART.py:345-353 (cos(tts pi/180) there)
   }
 }
 
