@@ -138,9 +138,11 @@ template <typename T> struct MatPtrs {
 // for vmcnt(0) -- i.e. for every outstanding store of the previous sample -- once per sample, which serialises the
 // store stream with the arithmetic.
 // fp64: left alone hipcc takes 262 VGPRs = ONE wave per SIMD; asking for two workgroups per CU (256 VGPRs, 7 spilled)
-// makes the fp64 mode 24 % faster (50.7 -> 38.6 ms per 1M spectra); three (168 VGPRs, 96 spilled) is 2.7x slower.
+// made the fp64 mode 24 % faster (50.7 -> 38.6 ms per 1M spectra); with the plate-model coefficients in constant
+// memory (spart_math.h, E3c<double>) three fit with 38 spilled values: 36.2 ms (with the coefficients as literals
+// three workgroups meant 96 spilled values and 104 ms).
 template <typename T, int MAT, int FULL>
-__global__ __launch_bounds__(TILE, (sizeof(T) == 8 ? 2 : 1))
+__global__ __launch_bounds__(TILE, (sizeof(T) == 8 ? 3 : 1))
 void k_bands(const T* __restrict__ tab, const T* __restrict__ cst,
                                                 const int* __restrict__ need_slot, int nslot, T* __restrict__ G,
                                                 int64_t B, int chunk, MatPtrs<T> mat, T* __restrict__ bandsum) {

@@ -265,11 +265,31 @@ template <> struct E3c<float> {
   static SPART_HD float p(int i) { return E3_P_F32[i]; }
   static SPART_HD float q(int i) { return E3_Q_F32[i]; }
 };
+#if defined(__HIPCC__)
+// The 27 float64 coefficients of the plate transmittance live in constant memory on the device: they arrive through
+// scalar loads and enter the FMAs as SGPR operands.  As literals they were parked in 54 VGPRs for the whole sample
+// loop and copied before every Horner step (v_fmac_f64 overwrites its addend); without them the float64 band kernel
+// fits three waves per SIMD with 38 spilled values instead of two with 7 (38.4 -> 36.2 ms per 1M spectra).  Doing
+// the same to the smaller polynomials (log1p, 1 - e^-z, phi) measured slower: their scalar loads sit in rarely
+// taken branches.  (float32 coefficients are instruction literals and cost nothing.)
+static_assert(E3_G_DEG_F64 == 12 && E3_W_DEG_F64 == 6, "tables below list the coefficients one by one");
+#define SPART_L13(a) {a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], a[10], a[11], a[12]}
+#define SPART_L7(a) {a[0], a[1], a[2], a[3], a[4], a[5], a[6]}
+__device__ __constant__ double c_E3_G_F64[13] = SPART_L13(E3_G_F64);
+__device__ __constant__ double c_E3_P_F64[7] = SPART_L7(E3_P_F64);
+__device__ __constant__ double c_E3_Q_F64[7] = SPART_L7(E3_Q_F64);
+#endif
 template <> struct E3c<double> {
   static constexpr int GD = E3_G_DEG_F64, WD = E3_W_DEG_F64;
+#if defined(__HIP_DEVICE_COMPILE__)
+  static SPART_HD double g(int i) { return c_E3_G_F64[i]; }
+  static SPART_HD double p(int i) { return c_E3_P_F64[i]; }
+  static SPART_HD double q(int i) { return c_E3_Q_F64[i]; }
+#else
   static SPART_HD double g(int i) { return E3_G_F64[i]; }
   static SPART_HD double p(int i) { return E3_P_F64[i]; }
   static SPART_HD double q(int i) { return E3_Q_F64[i]; }
+#endif
 };
 
 template <typename T> SPART_HD void plate_tau(T K, T& tau, T& u) {

@@ -1,7 +1,7 @@
 """Occupancy guard (no GPU needed: hipcc cross-compiles): the register budgets the performance numbers rest on.
 
 The band kernel's speed depends on resident waves per SIMD (512 VGPRs / wave budget): 5 for the float32 kernels
-(<= 96 VGPRs, no scratch), 2 for the float64 ones (<= 256).  A change that silently pushes a kernel over the edge
+(<= 96 VGPRs, no scratch), 3 for the float64 ones (<= 168).  A change that silently pushes a kernel over the edge
 would only show up as a slower benchmark; this test makes it a failure on the build machine."""
 import os
 import re
@@ -55,10 +55,10 @@ def test_float32_band_kernels_keep_five_waves_per_simd(kernel_meta):
             assert k["private_segment_fixed_size"] == 0 and k["vgpr_spill_count"] == 0, (frag, k)
 
 
-def test_float64_band_kernels_keep_two_waves_per_simd(kernel_meta):
+def test_float64_band_kernels_keep_three_waves_per_simd(kernel_meta):
     for k in _find(kernel_meta, "k_bandsIdLi0ELi1E"):
-        assert k["vgpr_count"] <= 256, k
-        assert k["private_segment_fixed_size"] <= 64, k        # a handful of spilled values, not a spilled loop
+        assert k["vgpr_count"] <= 168, k
+        assert k["private_segment_fixed_size"] <= 256, k       # a few dozen spilled values, not a spilled loop
 
 
 def test_sensor_kernel_fits_sixteen_waves(kernel_meta):
