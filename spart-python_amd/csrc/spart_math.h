@@ -142,10 +142,60 @@ template <> struct Mx<float> {
   static SPART_HD float tiny() { return 1e-30f; }
 };
 
+#if defined(__HIPCC__)
+// exp / log for the float64 band arithmetic (device, SPART_FAST_MATH): the usual range reductions with their polynomial
+// coefficients in constant memory (scalar loads -> SGPR operands, no VGPRs parked on constants, no copy before each
+// Horner step as with the library versions).  exp(x) is 0 below x = -745 (including -inf), NaN
+// propagates; log is only called with positive finite arguments.  Relative error <= 2e-16.
+__device__ __constant__ double c_EXP_F64[12] = {1.0 / 2, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320,
+                                                1.0 / 362880, 1.0 / 3628800, 1.0 / 39916800, 1.0 / 479001600, 1.0 / 6227020800.0};
+__device__ __constant__ double c_LOG_F64[9] = {1.0 / 3, 1.0 / 5, 1.0 / 7, 1.0 / 9, 1.0 / 11, 1.0 / 13, 1.0 / 15, 1.0 / 17, 1.0 / 19};
+#endif
+
 template <> struct Mx<double> {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(SPART_FAST_MATH)
+  static SPART_HD double exp_scaled(double x, double inv_ln_b, double ln_b_hi, double ln_b_lo) {
+    // b^k * e^r with k = rint(x / ln 2), |r| <= ln 2 / 2: Taylor to r^13 (r^14/14! < 4e-18)
+    x = (x < -800.0) ? -800.0 : x;                          // e^-800 underflows to 0 below; a NaN stays a NaN
+    const double k = __builtin_rint(x * inv_ln_b);
+    double r = __builtin_fma(-k, ln_b_hi, x);
+    r = __builtin_fma(-k, ln_b_lo, r);
+    double p = c_EXP_F64[11];
+#pragma unroll
+    for (int i = 10; i >= 0; --i) p = __builtin_fma(p, r, c_EXP_F64[i]);
+    p = __builtin_fma(p * r, r, r);                       // r + r^2 (1/2 + ...)
+    return __builtin_ldexp(1.0 + p, (int)k);
+  }
+  static SPART_HD double exp(double x) {
+    return exp_scaled(x, 1.4426950408889634, 6.93147180369123816490e-01, 1.90821492927058770002e-10);
+  }
+  static SPART_HD double exp2(double x) {                  // 2^x = e^(x ln 2)
+    const double k = __builtin_rint(x);
+    const double r = (x - k) * 0.6931471805599453;
+    double p = c_EXP_F64[11];
+#pragma unroll
+    for (int i = 10; i >= 0; --i) p = __builtin_fma(p, r, c_EXP_F64[i]);
+    p = __builtin_fma(p * r, r, r);
+    return __builtin_ldexp(1.0 + p, (int)k);
+  }
+  static SPART_HD double log(double x) {
+    // x = m 2^e with m in [sqrt(1/2), sqrt(2)); ln m = 2 atanh(s), s = (m - 1)/(m + 1), |s| <= 0.172 (s^21/21 < 5e-18)
+    int e;
+    double m = __builtin_frexp(x, &e);                     // m in [0.5, 1)
+    if (m < 0.7071067811865476) { m *= 2.0; e -= 1; }
+    const double s = (m - 1.0) * rcp(m + 1.0), s2 = s * s;
+    double p = c_LOG_F64[8];
+#pragma unroll
+    for (int i = 7; i >= 0; --i) p = __builtin_fma(p, s2, c_LOG_F64[i]);
+    p = __builtin_fma(p * s2, s, s);                       // s + s^3 (1/3 + ...)
+    const double ed = (double)e;
+    return __builtin_fma(ed, 6.93147180369123816490e-01, __builtin_fma(ed, 1.90821492927058770002e-10, 2.0 * p));
+  }
+#else
   static SPART_HD double exp(double x) { return ::exp(x); }
   static SPART_HD double exp2(double x) { return ::exp2(x); }
   static SPART_HD double log(double x) { return ::log(x); }
+#endif
   static SPART_HD double sqrt(double x) { return ::sqrt(x); }
   // reciprocal: v_rcp_f64 refined by two Newton steps (~1 ulp for normal arguments, 5 instructions) instead of
   // the ~12-instruction IEEE division sequence; the host build divides
