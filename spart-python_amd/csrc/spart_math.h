@@ -224,7 +224,7 @@ template <> struct Mx<double> {
       p = p * s2 + 1.0;
       return 2.0 * s * p;
     }
-    return ::log(1.0 + x);
+    return log(1.0 + x);
 #else
     return ::log1p(x);
 #endif
@@ -243,7 +243,7 @@ template <> struct Mx<double> {
       p = p * z + 1.0;
       return z * p;
     }
-    return 1.0 - ::exp(-z);
+    return 1.0 - exp(-z);
 #else
     return -::expm1(-z);
 #endif
