@@ -773,8 +773,8 @@ struct PsoFn {
   double A, C, alpha;
   bool hot;  // dso == 0
   SPART_HD double operator()(double x) const {
-    if (hot) return ::exp(A * x);  // A holds (K+k-sqrt(Kk)) LAI in this branch (:127)
-    return ::exp(A * x + C * Mx<double>::one_minus_exp_neg(-alpha * x));  // :121-125 (x <= 0)
+    if (hot) return Mx<double>::exp(A * x);  // A holds (K+k-sqrt(Kk)) LAI in this branch (:127)
+    return Mx<double>::exp(A * x + C * Mx<double>::one_minus_exp_neg(-alpha * x));  // :121-125 (x <= 0)
   }
 };
 
