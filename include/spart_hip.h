@@ -86,6 +86,13 @@ typedef struct spart_materialize {
   int32_t prune_unused_bands;  /* 0 (default): every one of the 2162 bands of every sample is evaluated and
                                   feeds band_mean's per-chunk sums; 1: bands that no requested output needs
                                   may be skipped (columns are identical, the work is not "full spectra") */
+  int32_t f32_columns;         /* dtype SPART_F32 only.  0 (default): the <= 2 nb spectral bands the sensor columns
+                                  depend on (np.interp support points, SPART.py:220-223) are evaluated in float64 on
+                                  top of the float32 full-band pass, so R_TOC / R_TOA / L_TOA are the float64 mode's
+                                  values rounded once to float32 (the 1e-4 contract then also holds for nearly
+                                  conservative PROSPECT-PRO leaves, where the reference's canopy formulas cancel,
+                                  sailh.py:185-214); materialised spectra and band_mean stay float32 arithmetic.
+                                  1: the columns are taken from the float32 band arithmetic itself */
 } spart_materialize;
 
 int spart_ctx_create(spart_ctx **out, int device, const spart_tables *tables);

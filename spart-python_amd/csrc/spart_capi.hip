@@ -106,10 +106,14 @@ struct DeviceGuard {
   }
 };
 
+// the band kernels address 8 rows of the float64 constant block with a 32-bit byte offset (stage_constants)
+constexpr int64_t SPART_MAX_BATCH = 60000000;
+
 inline size_t align_up(size_t x) { return (x + 255) & ~size_t(255); }
 
 struct Workspace {
-  size_t cst_off, atm_off, g_off, gs_off, bs_off, total;
+  size_t cstf_off, cstd_off, atm_off, g_off, gs_off, bs_off, total;
+  int64_t Bp;       // row pitch of the structure-of-arrays blocks (spart_kernels.h)
 };
 
 // the band kernels address a chunk's rows with a 32-bit byte offset per lane
@@ -135,11 +139,16 @@ int pick_chunk(int64_t B) {
 Workspace carve(int dtype, int64_t B, int nslot) {
   size_t es = dtype == SPART_F64 ? 8 : 4;
   Workspace w;
+  w.Bp = row_pitch_of(B);
+  const size_t Bp = (size_t)w.Bp, ns = (size_t)(nslot > 0 ? nslot : 1);
   size_t o = 0;
-  w.cst_off = o; o = align_up(o + (size_t)B * NCONST * es);
-  w.atm_off = o; o = align_up(o + (size_t)B * NATM * 8);
-  w.g_off = o;   o = align_up(o + (size_t)B * (size_t)(nslot > 0 ? nslot : 1) * 4 * es);
-  w.gs_off = o;  o = align_up(o + (size_t)B * (size_t)(nslot > 0 ? nslot : 1) * es);
+  // float32 constants only in the float32 modes; the float64 constants, the G rows and the rsoil slots are sized for
+  // float64 in both (the default float32 mode keeps them in float64: k_slots<double>)
+  w.cstf_off = o; o = align_up(o + (dtype == SPART_F64 ? 0 : Bp * NCONST * 4));
+  w.cstd_off = o; o = align_up(o + Bp * NCONST * 8);
+  w.atm_off = o;  o = align_up(o + Bp * NATM * 8);
+  w.g_off = o;    o = align_up(o + Bp * ns * 4 * 8);
+  w.gs_off = o;   o = align_up(o + Bp * ns * 8);
   int chunk = pick_chunk(B);
   size_t nchunk = (size_t)((B + chunk - 1) / chunk);
   w.bs_off = o;  o = align_up(o + nchunk * (size_t)(NTILE * TILE) * 4 * es);
@@ -161,13 +170,22 @@ template <typename T> int upload(const spart_ctx* ctx, T** dst, const std::vecto
   return SPART_OK;
 }
 
-template <typename T>
-int launch_prelude(spart_ctx* ctx, const ParamPtrs& pp, int mask, int64_t B, T* cst, double* atm, double* lidf,
-                   hipStream_t st) {
+// fast: Newton LIDF / 8-point hot-spot rule (legacy float32 columns and the float32 stage-level entry points)
+int launch_prelude(spart_ctx* ctx, bool fast, const ParamPtrs& pp, int mask, int64_t B, int64_t Bp, float* cstF,
+                   double* cstD, double* atm, hipStream_t st) {
   unsigned grid = (unsigned)((B + 255) / 256);
-  hipLaunchKernelGGL((k_prelude<T>), dim3(grid), dim3(256), 0, st, pp, mask, B, cst, atm, lidf);
+  if (fast) hipLaunchKernelGGL((k_prelude<true>), dim3(grid), dim3(256), 0, st, pp, mask, B, Bp, cstF, cstD, atm);
+  else hipLaunchKernelGGL((k_prelude<false>), dim3(grid), dim3(256), 0, st, pp, mask, B, Bp, cstF, cstD, atm);
   HIP_TRY(ctx, hipGetLastError());
   return SPART_OK;
+}
+
+// the stage-level entry points: constants in the call's dtype
+template <typename T> T* stage_cst(char* wsp, const Workspace& ws) { return (T*)(wsp + (sizeof(T) == 4 ? ws.cstf_off : ws.cstd_off)); }
+template <typename T>
+int launch_stage_prelude(spart_ctx* ctx, const ParamPtrs& pp, int mask, int64_t B, char* wsp, const Workspace& ws, hipStream_t st) {
+  return launch_prelude(ctx, sizeof(T) == 4, pp, mask, B, ws.Bp, sizeof(T) == 4 ? (float*)(wsp + ws.cstf_off) : nullptr,
+                        sizeof(T) == 8 ? (double*)(wsp + ws.cstd_off) : nullptr, nullptr, st);
 }
 
 }  // namespace
@@ -178,14 +196,14 @@ static int prospect_impl(spart_ctx* ctx, int64_t B, const double* const leaf[9],
   ParamPtrs pp;
   std::memset(&pp, 0, sizeof(pp));
   for (int i = 0; i < 9; ++i) pp.p[i] = leaf[i];
-  T* cst = (T*)(wsp + ws.cst_off);
-  int rc = launch_prelude<T>(ctx, pp, PRE_LEAF, B, cst, nullptr, nullptr, st);
+  T* cst = stage_cst<T>(wsp, ws);
+  int rc = launch_stage_prelude<T>(ctx, pp, PRE_LEAF, B, wsp, ws, st);
   if (rc) return rc;
   int chunk = pick_chunk(B);
   int64_t nchunk = (B + chunk - 1) / chunk;
   const T* tab = sizeof(T) == 4 ? (const T*)ctx->tabF : (const T*)ctx->tabD;
   if (!chunk_fits_32bit(chunk, ctx->po, sizeof(T))) return fail(ctx, SPART_ERR_INVALID, "batch too large for one call");
-  hipLaunchKernelGGL((k_prospect<T>), dim3(xcd_grid(nchunk)), dim3(TILE), 0, st, tab, (const T*)cst, B, chunk,
+  hipLaunchKernelGGL((k_prospect<T>), dim3(xcd_grid(nchunk)), dim3(TILE), 0, st, tab, (const T*)cst, ws.Bp, B, chunk,
                      ctx->po, (T*)refl, (T*)tran, (T*)kchl);
   HIP_TRY(ctx, hipGetLastError());
   return SPART_OK;
@@ -197,14 +215,14 @@ static int bsm_impl(spart_ctx* ctx, int64_t B, const double* const soil[6], cons
   ParamPtrs pp;
   std::memset(&pp, 0, sizeof(pp));
   for (int i = 0; i < 6; ++i) pp.p[9 + i] = soil[i];
-  T* cst = (T*)(wsp + ws.cst_off);
-  int rc = launch_prelude<T>(ctx, pp, PRE_SOIL, B, cst, nullptr, nullptr, st);
+  T* cst = stage_cst<T>(wsp, ws);
+  int rc = launch_stage_prelude<T>(ctx, pp, PRE_SOIL, B, wsp, ws, st);
   if (rc) return rc;
   int chunk = pick_chunk(B);
   int64_t nchunk = (B + chunk - 1) / chunk;
   const T* tab = sizeof(T) == 4 ? (const T*)ctx->tabF : (const T*)ctx->tabD;
   if (!chunk_fits_32bit(chunk, ctx->po, sizeof(T))) return fail(ctx, SPART_ERR_INVALID, "batch too large for one call");
-  hipLaunchKernelGGL((k_bsm<T>), dim3(xcd_grid(nchunk)), dim3(TILE), 0, st, tab, (const T*)cst, B, chunk,
+  hipLaunchKernelGGL((k_bsm<T>), dim3(xcd_grid(nchunk)), dim3(TILE), 0, st, tab, (const T*)cst, ws.Bp, B, chunk,
                      ctx->po, (const T*)rdry_in, (T*)refl, (T*)dry);
   HIP_TRY(ctx, hipGetLastError());
   return SPART_OK;
@@ -218,49 +236,62 @@ static int sailh_impl(spart_ctx* ctx, int64_t B, const void* rho, const void* ta
   std::memset(&pp, 0, sizeof(pp));
   for (int i = 0; i < 4; ++i) pp.p[15 + i] = canopy[i];
   for (int i = 0; i < 3; ++i) pp.p[19 + i] = angles[i];
-  T* cst = (T*)(wsp + ws.cst_off);
-  int rc = launch_prelude<T>(ctx, pp, PRE_CANOPY, B, cst, nullptr, nullptr, st);
+  T* cst = stage_cst<T>(wsp, ws);
+  int rc = launch_stage_prelude<T>(ctx, pp, PRE_CANOPY, B, wsp, ws, st);
   if (rc) return rc;
   int chunk = pick_chunk(B);
   int64_t nchunk = (B + chunk - 1) / chunk;
   if (!chunk_fits_32bit(chunk, ctx->pf, sizeof(T))) return fail(ctx, SPART_ERR_INVALID, "batch too large for one call");
-  hipLaunchKernelGGL((k_sailh<T>), dim3((unsigned)(nchunk * NTILE_FULL)), dim3(TILE), 0, st, (const T*)cst, B, chunk,
+  hipLaunchKernelGGL((k_sailh<T>), dim3((unsigned)(nchunk * NTILE_FULL)), dim3(TILE), 0, st, (const T*)cst, ws.Bp, B, chunk,
                      ctx->pf, (const T*)rho, (const T*)tau, (const T*)rs, (T*)out4[0], (T*)out4[1], (T*)out4[2], (T*)out4[3]);
   HIP_TRY(ctx, hipGetLastError());
   return SPART_OK;
 }
 
-template <typename T>
+// T = dtype of the full-band kernel and of the outputs; TG = dtype of the prelude's constants, of the G rows at the
+// sensor slots and of the rsoil slots.  <double,double> = float64 mode; <float,double> = the default float32 mode
+// (sensor-slot bands re-evaluated in float64, k_bands_pruned); <float,float> = spart_materialize.f32_columns.
+template <typename T, typename TG>
 static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_NPARAM], const double* rho_th,
                     const double* tau_th, void* R_TOC, void* R_TOA, void* L_TOA, const spart_materialize* opt, char* wsp,
                     const Workspace& ws, hipStream_t st) {
+  constexpr bool HYBRID = sizeof(T) != sizeof(TG);
   ParamPtrs pp;
   for (int i = 0; i < NPARAM; ++i) pp.p[i] = params[i];
   pp.rho_th = rho_th;
   pp.tau_th = tau_th;
-  T* cst = (T*)(wsp + ws.cst_off);
+  const int64_t Bp = ws.Bp;
+  float* cstF = (float*)(wsp + ws.cstf_off);
+  double* cstD = (double*)(wsp + ws.cstd_off);
+  const T* cst = sizeof(T) == 4 ? (const T*)cstF : (const T*)cstD;       // the full-band kernel's constants
+  const TG* cstG = sizeof(TG) == 4 ? (const TG*)cstF : (const TG*)cstD;  // the slot pass's constants
   double* atm = (double*)(wsp + ws.atm_off);
-  T* G = (T*)(wsp + ws.g_off);
-  T* gs = (T*)(wsp + ws.gs_off);
+  TG* G = (TG*)(wsp + ws.g_off);
+  TG* gs = (TG*)(wsp + ws.gs_off);
   int rc;
   {
     Range r("SPART prelude (geometry, LIDF, hot spot, soil factors)");
-    rc = launch_prelude<T>(ctx, pp, PRE_ALL, B, cst, atm, nullptr, st);
+    // legacy float32 columns: the fast prelude; otherwise the literal one, so that the default float32 mode's
+    // columns are exactly the float64 mode's
+    rc = launch_prelude(ctx, sizeof(TG) == 4, pp, PRE_ALL, B, Bp, sizeof(T) == 4 ? cstF : nullptr,
+                        sizeof(TG) == 8 ? cstD : nullptr, atm, st);
   }
   if (rc) return rc;
   Range rb("SPART bands + sensor (BSM, PROSPECT, SAILH | interp, SMAC, TOC->TOA)");
   int chunk = pick_chunk(B);
   int64_t nchunk = (B + chunk - 1) / chunk;
   const T* tab = sizeof(T) == 4 ? (const T*)ctx->tabF : (const T*)ctx->tabD;
+  const TG* tabG = sizeof(TG) == 4 ? (const TG*)ctx->tabF : (const TG*)ctx->tabD;
   MatPtrs<T> mp;
   std::memset(&mp, 0, sizeof(mp));
   mp.pf = ctx->pf; mp.po = ctx->po;
   bool mat = false;
+  const bool want_rsoil = opt && opt->rsoil;
   if (opt) {
     mp.leaf_refl = (T*)opt->leaf_refl; mp.leaf_tran = (T*)opt->leaf_tran; mp.leaf_kchl = (T*)opt->leaf_kchl;
     mp.soil_refl = (T*)opt->soil_refl; mp.soil_dry = (T*)opt->soil_refl_dry;
     mp.rso = (T*)opt->rso; mp.rdo = (T*)opt->rdo; mp.rsd = (T*)opt->rsd; mp.rdd = (T*)opt->rdd;
-    mp.gsoil = opt->rsoil ? gs : nullptr;
+    mp.gsoil = (want_rsoil && !HYBRID) ? (T*)gs : nullptr;      // hybrid: the rsoil slots come from the slot pass
     mp.rdry_in = (const T*)opt->rdry_in;
     mat = mp.rdry_in || mp.leaf_refl || mp.leaf_tran || mp.leaf_kchl || mp.soil_refl || mp.soil_dry || mp.rso || mp.rdo || mp.rsd ||
           mp.rdd || mp.gsoil;
@@ -274,10 +305,12 @@ static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_
     return fail(ctx, SPART_ERR_INVALID, "spart_run_batch: band_mean needs prune_unused_bands = 0");
   const bool prof = ctx->profile && ctx->ev_used + 2 <= ctx->ev.size();
   if (prof) HIP_TRY(ctx, hipEventRecord(ctx->ev[ctx->ev_used], st));
+  // hybrid: the full-band kernel stores no G rows; they come from the float64 slot pass below
 #define SPART_LAUNCH_BANDS(M, F)                                                                                 \
-  hipLaunchKernelGGL((k_bands<T, M, F>), grid, dim3(TILE), 0, st, tab, (const T*)cst, (const int*)ctx->need_slot, \
-                     ctx->nslot, G, B, chunk, mp, bsum)
+  hipLaunchKernelGGL((k_bands<T, M, F, !HYBRID>), grid, dim3(TILE), 0, st, tab, cst, Bp, (const int*)ctx->need_slot, \
+                     ctx->nslot, (T*)(HYBRID ? nullptr : (void*)G), B, chunk, mp, bsum)
   const bool four = opt && opt->band_mean;     // the four band sums are only kept apart when their means are asked for
+  bool slots_done = !HYBRID;                   // (the non-hybrid band kernels write the G rows themselves)
   if (mat && mp.rdry_in && full && four) SPART_LAUNCH_BANDS(2, 2);
   else if (mat && mp.rdry_in && full) SPART_LAUNCH_BANDS(2, 1);
   else if (mat && mp.rdry_in) SPART_LAUNCH_BANDS(2, 0);
@@ -286,16 +319,19 @@ static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_
   else if (mat) SPART_LAUNCH_BANDS(1, 0);
   else if (full && four) SPART_LAUNCH_BANDS(0, 2);
   else if (full) SPART_LAUNCH_BANDS(0, 1);
-  else {   // columns only, pruning allowed: evaluate just the sensor's bands
-    int64_t n = B * ctx->nslot;
-    hipLaunchKernelGGL((k_bands_pruned<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, tab, (const T*)cst,
-                       (const int*)ctx->slot_band, ctx->nslot, G, B);
-  }
+  else slots_done = false;                     // columns only, pruning allowed: evaluate just the sensor's bands
 #undef SPART_LAUNCH_BANDS
   HIP_TRY(ctx, hipGetLastError());
   if (prof) {
     HIP_TRY(ctx, hipEventRecord(ctx->ev[ctx->ev_used + 1], st));
     ctx->ev_used += 2;
+  }
+  if (!slots_done) {
+    const int64_t nblk = (B + 255) / 256;                              // 256-sample blocks, dealt to the XCDs in groups of 8
+    hipLaunchKernelGGL((k_slots<TG, T>), dim3((unsigned)(((nblk + 7) / 8) * 8 * ctx->nslot)), dim3(256), 0, st, tabG,
+                       cstG, Bp, (const int*)ctx->slot_band, G, (TG*)(want_rsoil ? gs : nullptr),
+                       (const T*)(opt ? opt->rdry_in : nullptr), ctx->po, B, ctx->nslot);
+    HIP_TRY(ctx, hipGetLastError());
   }
   if (opt && opt->band_mean) {
     hipLaunchKernelGGL((k_bandmean<T>), dim3((4 * NWLS + 255) / 256), dim3(256), 0, st, (const T*)bsum, nchunk, B,
@@ -304,15 +340,16 @@ static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_
   }
   SensorTab stb{ctx->slot0, ctx->slot1, ctx->frac, ctx->coef, ctx->econv, ctx->nb, ctx->nslot};
   {
-    const bool want_rsoil = opt && opt->rsoil;
     const int narr = 3 + (want_rsoil ? 1 : 0) + ((opt && opt->La) ? 1 : 0);
     const size_t lds = (size_t)narr * 64 * ctx->nb * sizeof(T);      // <= 5 * 64 * 64 * 8 = 160 KiB only for nb = 64 fp64
     if (lds > 64 * 1024) return fail(ctx, SPART_ERR_INVALID, "spart_run_batch: %d sensor bands need %zu B of LDS staging", ctx->nb, lds);
     // 4 waves (each walking every 4th band) per 64-sample workgroup: with one wave per band (13 for Sentinel-2) a
     // CU holds a single workgroup and the kernel is 0.25 ms per 1M spectra slower (sweep 2..13: 2-4 equal)
     const int nwave = ctx->nb < 4 ? ctx->nb : 4;
-    hipLaunchKernelGGL((k_sensor<T>), dim3((unsigned)((B + 63) / 64)), dim3(64 * nwave), lds, st, stb, (const T*)G,
-                       (const double*)atm, B, (T*)R_TOC, (T*)R_TOA, (T*)L_TOA, (const T*)(want_rsoil ? gs : nullptr),
+    const GLayout gl = slots_done ? GLayout{4, 1, (int64_t)ctx->nslot * 4, 1, (int64_t)ctx->nslot}     // written by k_bands
+                                  : GLayout{4 * Bp, Bp, 1, Bp, 1};                                       // written by k_slots
+    hipLaunchKernelGGL((k_sensor<T, TG>), dim3((unsigned)((B + 63) / 64)), dim3(64 * nwave), lds, st, stb, (const TG*)G, gl,
+                       (const double*)atm, Bp, B, (T*)R_TOC, (T*)R_TOA, (T*)L_TOA, (const TG*)(want_rsoil ? gs : nullptr),
                        (T*)(opt ? opt->rsoil : nullptr), (T*)(opt ? opt->La : nullptr));
   }
   HIP_TRY(ctx, hipGetLastError());
@@ -550,6 +587,7 @@ size_t spart_workspace_bytes(const spart_ctx* ctx, int dtype, int64_t B) {
 
 #define CHECK_COMMON(name)                                                                                  \
   if (!ctx) return fail(nullptr, SPART_ERR_INVALID, name ": null context");                                 \
+  if (B > SPART_MAX_BATCH) return fail(ctx, SPART_ERR_INVALID, name ": at most %lld samples per call", (long long)SPART_MAX_BATCH); \
   if (dtype != SPART_F32 && dtype != SPART_F64) return fail(ctx, SPART_ERR_INVALID, name ": bad dtype %d", dtype); \
   if (B < 0) return fail(ctx, SPART_ERR_INVALID, name ": negative batch");                                  \
   if (B == 0) return SPART_OK;                                                                              \
@@ -619,15 +657,14 @@ int spart_smac_batch(spart_ctx* ctx, int64_t B, const double* const angles[3], c
   std::memset(&pp, 0, sizeof(pp));
   for (int i = 0; i < 3; ++i) pp.p[19 + i] = angles[i];
   for (int i = 0; i < 4; ++i) pp.p[22 + i] = atm[i];
-  double* cst = (double*)(wsp + ws.cst_off);
   double* a = (double*)(wsp + ws.atm_off);
-  int rc = launch_prelude<double>(ctx, pp, PRE_ATM, B, cst, a, nullptr, st);
+  int rc = launch_prelude(ctx, false, pp, PRE_ATM, B, ws.Bp, nullptr, nullptr, a, st);
   if (rc) return rc;
   Out9 o;
   for (int i = 0; i < 9; ++i) o.o[i] = out9[i];
   int64_t n = B * ctx->nb;
   hipLaunchKernelGGL(k_smac, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)ctx->coef, ctx->nb,
-                     (const double*)a, B, o);
+                     (const double*)a, ws.Bp, B, o);
   HIP_TRY(ctx, hipGetLastError());
   return SPART_OK;
 }
@@ -642,9 +679,10 @@ int spart_run_batch(spart_ctx* ctx, int dtype, int64_t B, const double* const pa
   for (int i = 0; i < SPART_NPARAM; ++i)
     if (!params[i] && !(opt && opt->rdry_in && i >= 9 && i <= 11))   // B, lat, lon are unused with user dry spectra
       return fail(ctx, SPART_ERR_INVALID, "spart_run_batch: params[%d] is null", i);
-  return dtype == SPART_F32
-             ? run_impl<float>(ctx, B, params, rho_thermal, tau_thermal, R_TOC, R_TOA, L_TOA, opt, wsp, ws, st)
-             : run_impl<double>(ctx, B, params, rho_thermal, tau_thermal, R_TOC, R_TOA, L_TOA, opt, wsp, ws, st);
+  if (dtype == SPART_F64) return run_impl<double, double>(ctx, B, params, rho_thermal, tau_thermal, R_TOC, R_TOA, L_TOA, opt, wsp, ws, st);
+  return (opt && opt->f32_columns)
+             ? run_impl<float, float>(ctx, B, params, rho_thermal, tau_thermal, R_TOC, R_TOA, L_TOA, opt, wsp, ws, st)
+             : run_impl<float, double>(ctx, B, params, rho_thermal, tau_thermal, R_TOC, R_TOA, L_TOA, opt, wsp, ws, st);
 }
 
 size_t spart_lut_workspace_bytes(int dtype, int64_t B, int nb, int64_t M) {

@@ -36,33 +36,70 @@ struct ParamPtrs {
 };
 
 // ------------------------------------------------------------------------------------------
-// K1: one lane per sample, float64: parameters -> band constants + atmosphere scalars
+// Workspace layout of the per-sample quantities: STRUCTURE OF ARRAYS with row pitch Bp (= B rounded up to 64):
+//   cst[i][s]  (48 rows, float and / or double), atm[i][s] (16 rows, double), G[slot][4][s], gsoil[slot][s].
+// Every kernel that has the sample on its lanes (prelude, sensor-slot pass, sensor kernel) then reads and writes
+// them coalesced; the band kernels (band on lanes) stage 32 samples x 48 constants per workgroup copy.
+inline int64_t row_pitch_of(int64_t B) { return (B + 63) & ~int64_t(63); }
+
+// A sample's constants seen from a band kernel: either contiguous in LDS (plain pointer) or column s of the
+// structure-of-arrays block (wave-uniform address -> scalar loads).
+template <typename T> struct ConstCol {
+  const T* p;
+  int64_t stride;
+  __device__ __forceinline__ T operator[](int i) const { return p[(int64_t)i * stride]; }
+};
+
+// One workgroup copy of 32 samples x 48 constants from the structure-of-arrays block (blk = &cst[0][first sample]) into
+// LDS as [sample][48]: lanes 32 r .. 32 r + 31 read 128 contiguous bytes of row r + 8 k.  The row base is wave-uniform
+// (SGPRs) and the lane carries ONE loop-invariant 32-bit byte offset (host: 8 Bp sizeof(T) < 4 GB), so nothing but
+// that register stays live across the sample loop.
 template <typename T>
-__global__ __launch_bounds__(256) void k_prelude(ParamPtrs pp, int mask, int64_t B, T* __restrict__ cst,
-                                                 double* __restrict__ atm, double* __restrict__ lidf) {
+__device__ __forceinline__ void stage_constants(T* lds_c, const T* __restrict__ blk, int64_t Bp, int nsub) {
+  static_assert(TILE == 256 && NCONST % 8 == 0, "8 rows of 32 samples per pass");
+  const int si = threadIdx.x & 31, i0 = threadIdx.x >> 5;
+  const unsigned lane_off = ((unsigned)i0 * (unsigned)Bp + (unsigned)si) * (unsigned)sizeof(T);
+  if (si < nsub) {
+#pragma unroll
+    for (int k = 0; k < NCONST / 8; ++k) {
+      const T* row = blk + (int64_t)(8 * k) * Bp;
+      lds_c[si * NCONST + i0 + 8 * k] = *reinterpret_cast<const T*>(reinterpret_cast<const char*>(row) + lane_off);
+    }
+  }
+}
+
+// K1: one lane per sample, float64: parameters -> band constants + atmosphere scalars.
+// FAST: Newton LIDF + 8-point hot-spot panels (~1e-7 from the literal forms; only the legacy float32-columns mode),
+// otherwise the reference's own LIDF iteration and 16-point panels.  The constants are computed in float64 and
+// written in float32 (cstF, for the float32 band kernels) and / or float64 (cstD: float64 band kernels and the
+// float64 sensor-slot pass of the default float32 mode).
+struct PreludeStore {            // sample_prelude_to's sink: straight to the structure-of-arrays workspace
+  float* cstF;
+  double* cstD;
+  double* atm;
+  int64_t Bp, s;
+  __device__ __forceinline__ void c(int i, double v) const {
+    if (cstF) cstF[i * Bp + s] = (float)v;
+    if (cstD) cstD[i * Bp + s] = v;
+  }
+  __device__ __forceinline__ void a(int i, double v) const {
+    if (atm) atm[i * Bp + s] = v;
+  }
+  __device__ __forceinline__ void l(int, double) const {}
+};
+
+#ifndef SPART_PRELUDE_WAVES
+#define SPART_PRELUDE_WAVES 3     // waves per SIMD the prelude is compiled for (168 VGPRs, a handful of spilled values)
+#endif
+template <bool FAST>
+__global__ __launch_bounds__(256, SPART_PRELUDE_WAVES) void k_prelude(ParamPtrs pp, int mask, int64_t B, int64_t Bp, float* __restrict__ cstF,
+                                                 double* __restrict__ cstD, double* __restrict__ atm) {
   int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= B) return;
-  double p[NPARAM];
-#pragma unroll
-  for (int i = 0; i < NPARAM; ++i) p[i] = pp.p[i] ? pp.p[i][s] : 0.0;
   double rho_th = pp.rho_th ? pp.rho_th[s] : 0.01;  // LeafBiology defaults (prospect_5d.py:82-83)
   double tau_th = pp.tau_th ? pp.tau_th[s] : 0.01;
-  T c[NCONST];
-  double a[NATM];
-  double li[NLINCL];
-  sample_prelude<T, (sizeof(T) == 4)>(p, rho_th, tau_th, mask, c, a, li);
-  // constants: 48 values per sample (written once, read by 8 workgroups through s_load)
-  T* dst = cst + s * NCONST;
-#pragma unroll
-  for (int i = 0; i < NCONST; ++i) dst[i] = c[i];
-  if (atm) {
-#pragma unroll
-    for (int i = 0; i < NATM; ++i) atm[s * NATM + i] = a[i];
-  }
-  if (lidf) {
-#pragma unroll
-    for (int i = 0; i < NLINCL; ++i) lidf[s * NLINCL + i] = li[i];
-  }
+  PreludeStore out{cstF, cstD, atm, Bp, s};
+  sample_prelude_to<FAST>([&pp, s](int i) { return pp.p[i] ? pp.p[i][s] : 0.0; }, rho_th, tau_th, mask, out);
 }
 
 // leaf-angle distribution only (CanopyStructure.lidf, sailh.py:348)
@@ -99,7 +136,7 @@ template <typename T> __device__ __forceinline__ BandTab<T> load_tab(const T* __
   return t;
 }
 
-template <typename T> __device__ __forceinline__ CanopyPar<T> load_canopy(const T* __restrict__ c) {
+template <typename T, typename C> __device__ __forceinline__ CanopyPar<T> load_canopy(const C& c) {
   CanopyPar<T> cp;
   cp.sob = c[C_SOB]; cp.sof = c[C_SOF];
   cp.hbf = c[C_HBF]; cp.ks = c[C_KS]; cp.ko = c[C_KO]; cp.lai = c[C_LAI]; cp.lai2 = c[C_LAI2];
@@ -141,9 +178,12 @@ template <typename T> struct MatPtrs {
 // made the fp64 mode 24 % faster (50.7 -> 38.6 ms per 1M spectra); with the plate-model coefficients in constant
 // memory (spart_math.h, E3c<double>) three fit with 38 spilled values: 36.2 ms (with the coefficients as literals
 // three workgroups meant 96 spilled values and 104 ms).
-template <typename T, int MAT, int FULL>
+// need_slot: eval index -> sensor slot or -1.  In the default float32 mode the sensor columns do not come from this
+// kernel at all (SLOTS = false) but from k_slots<double> over the float64 constants.
+// SLOTS = false: this kernel stores no G rows (and no rsoil slots) at all.
+template <typename T, int MAT, int FULL, bool SLOTS>
 __global__ __launch_bounds__(TILE, (sizeof(T) == 8 ? 3 : 1))
-void k_bands(const T* __restrict__ tab, const T* __restrict__ cst,
+void k_bands(const T* __restrict__ tab, const T* __restrict__ cst, int64_t Bp,
                                                 const int* __restrict__ need_slot, int nslot, T* __restrict__ G,
                                                 int64_t B, int chunk, MatPtrs<T> mat, T* __restrict__ bandsum) {
   int tile;
@@ -155,7 +195,7 @@ void k_bands(const T* __restrict__ tab, const T* __restrict__ cst,
   const bool thermal = band == NWL;                    // the single thermal evaluation
   const int ti = band < NWL ? band : NWL - 1;          // thermal soil = soil at 2400 nm (SPART.py:440)
   const BandTab<T> tb = load_tab(tab, ti);
-  const int slot = active ? need_slot[band] : -1;
+  const int slot = (SLOTS && active) ? need_slot[band] : -1;
   const int64_t s0 = ck * chunk;
   const int64_t s1 = (s0 + chunk < B) ? s0 + chunk : B;
   T sum_so = T(0), sum_do = T(0), sum_sd = T(0), sum_dd = T(0);
@@ -184,7 +224,7 @@ void k_bands(const T* __restrict__ tab, const T* __restrict__ cst,
   for (int64_t sb = s0; sb < s1; sb += SUB) {
   const int nsub = (int)((s1 - sb < SUB) ? (s1 - sb) : SUB);
   __syncthreads();                                     // the previous sub-chunk has been consumed by every wave
-  for (int i = threadIdx.x; i < nsub * NCONST; i += TILE) lds_c[i] = cst[sb * NCONST + i];
+  stage_constants<T>(lds_c, cst + sb, Bp, nsub);
   __syncthreads();
   // the nine leaf constants are read one sample ahead (they are the first thing an iteration needs: without the
   // prefetch every iteration starts by waiting for its own LDS reads).  Not in the materialising variants: there the
@@ -223,7 +263,7 @@ void k_bands(const T* __restrict__ tab, const T* __restrict__ cst,
     }
     // order: leaf -> canopy solve for the leaf alone -> soil -> coupling with the soil background.  The soil model
     // sits between the two canopy parts because that schedule measured fastest (interleaved A/B of four orders).
-    const CanopyPar<T> cp = load_canopy(c);
+    const CanopyPar<T> cp = load_canopy<T>(c);
     const CanopyCore<T> core = canopy_core<T>(cp, rho, tau, ab);
     T rdry = (MAT == 2) ? mat.rdry_in[s * mat.po + ti] : soil_dry<T>(tb, c[C_F1], c[C_F2], c[C_F3]);
     T fm[7] = {c[C_FM0], c[C_FM1], c[C_FM2], c[C_FM3], c[C_FM4], c[C_FM5], c[C_FM6]};
@@ -240,8 +280,8 @@ void k_bands(const T* __restrict__ tab, const T* __restrict__ cst,
     } else if (FULL == 1) {
       sum_so += (rso + rdo) + (rsd + rdd);
     }
-    if (slot >= 0) {
-      T* g = G + (s * nslot + slot) * 4;
+    if (SLOTS && slot >= 0) {
+      T* g = G + (s * nslot + slot) * 4;                 // G[B][nslot][4] (k_sensor: GLayout)
       g[0] = rso; g[1] = rdo; g[2] = rsd; g[3] = rdd;
     }
     if (MAT) {
@@ -250,7 +290,7 @@ void k_bands(const T* __restrict__ tab, const T* __restrict__ cst,
         if (mat.rdo) store_row(mat.rdo, off_f, rdo);
         if (mat.rsd) store_row(mat.rsd, off_f, rsd);
         if (mat.rdd) store_row(mat.rdd, off_f, rdd);
-        if (mat.gsoil && slot >= 0) (mat.gsoil + s * nslot)[slot] = rwet;
+        if (SLOTS && mat.gsoil && slot >= 0) (mat.gsoil + s * nslot)[slot] = rwet;
       }
       // thermal padding (SPART.py:427-470): the wave that holds the thermal evaluation (band 2001) copies it over
       // bands 2002..2161 of the padded spectra -- 160 values per array, three coalesced stores per lane
@@ -284,38 +324,50 @@ void k_bands(const T* __restrict__ tab, const T* __restrict__ cst,
   }
 }
 
-// Pruned mode (spart_materialize.prune_unused_bands = 1, NOT "full spectra"): only the <= 2 nb bands the sensor
-// columns depend on are evaluated -- one lane per (sample, slot); the band's table row is gathered and the
-// sample's constants are read per lane (neighbouring lanes share them through L1).  Identical arithmetic
-// (leaf_band / soil_band / canopy_band), identical G rows, ~150x less work than k_bands.
-template <typename T>
-__global__ __launch_bounds__(256) void k_bands_pruned(const T* __restrict__ tab, const T* __restrict__ cst,
-                                                      const int* __restrict__ slot_band, int nslot,
-                                                      T* __restrict__ G, int64_t B) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B * nslot) return;
-  const int64_t s = i / nslot;
-  const int q = (int)(i - s * nslot);
+// The sensor-slot pass: only the <= 2 nb bands the sensor columns depend on are evaluated.  Lane = sample, one
+// workgroup = 256 samples x ONE slot: the band's 17 table values are wave-uniform (scalar loads), the sample's
+// constants and the G rows are read / written coalesced (structure of arrays).  Block map (XCD-aware, cdna guide T1):
+// the nslot workgroups of one 256-sample block get ids x, x + 8, ..., i.e. the same XCD back to back, so that the
+// block's 40 constants x 256 samples are fetched from HBM once and re-read from that XCD's L2 (with the slot on
+// blockIdx.y the kernel moved nslot x 320 B per sample through HBM / MALL and was bound by that: 0.57 ms per 1M).  Identical arithmetic (leaf_band / soil_band /
+// canopy_band), ~150x less work than k_bands.  Two uses:
+//   * T = double in the default float32 mode: the G rows (and the debug rsoil values) that k_sensor turns into
+//     R_TOC / R_TOA / L_TOA are float64 whatever the dtype of the full-band kernel, so the float32 mode's columns are
+//     the float64 mode's columns rounded once (near-conservative PRO leaves make the
+//     reference's canopy formulas cancel, sailh.py:185-214, and float32 band arithmetic then misses 1e-4);
+//   * spart_materialize.prune_unused_bands = 1 (NOT "full spectra"): the full-band kernel is skipped altogether.
+// TR: element type of the optional user dry-soil spectra (they arrive in the call's dtype).
+template <typename T, typename TR>
+__global__ __launch_bounds__(256) void k_slots(const T* __restrict__ tab, const T* __restrict__ cst, int64_t Bp,
+                                               const int* __restrict__ slot_band, T* __restrict__ G,
+                                               T* __restrict__ gsoil, const TR* __restrict__ rdry_in, int po, int64_t B,
+                                               int nslot) {
+  const unsigned per = 8u * (unsigned)nslot, within = blockIdx.x % per;
+  const int q = (int)(within >> 3);
+  const int64_t s = ((int64_t)(blockIdx.x / per) * 8 + (within & 7u)) * blockDim.x + threadIdx.x;
+  if (s >= B) return;
   const int band = slot_band[q];
   const bool thermal = band == NWL;
-  const BandTab<T> tb = load_tab(tab, band < NWL ? band : NWL - 1);
-  const T* __restrict__ c = cst + s * NCONST;
+  const int ti = band < NWL ? band : NWL - 1;
+  const BandTab<T> tb = load_tab(tab, ti);
+  const ConstCol<T> c{cst + s, Bp};
   T refl, tran, absb, K;
   leaf_band<T>(tb, c[C_CAB], c[C_CCA], c[C_CDM], c[C_CW], c[C_CS], c[C_CANT], c[C_CBC], c[C_PROT], c[C_NM1], refl,
                tran, absb, K);
   T rho = thermal ? c[C_RHO_TH] : refl;
   T tau = thermal ? c[C_TAU_TH] : tran;
   T ab = thermal ? (T(1) - c[C_RHO_TH] - c[C_TAU_TH]) : absb;
-  const CanopyPar<T> cp = load_canopy(c);                      // (same order of the parts as in k_bands)
+  const CanopyPar<T> cp = load_canopy<T>(c);                   // (same order of the parts as in k_bands)
   const CanopyCore<T> core = canopy_core<T>(cp, rho, tau, ab);
-  T rdry = soil_dry<T>(tb, c[C_F1], c[C_F2], c[C_F3]);
+  T rdry = rdry_in ? (T)rdry_in[s * po + ti] : soil_dry<T>(tb, c[C_F1], c[C_F2], c[C_F3]);
   T fm[7] = {c[C_FM0], c[C_FM1], c[C_FM2], c[C_FM3], c[C_FM4], c[C_FM5], c[C_FM6]};
   T rwet;
   soil_band<T>(tb, rdry, c[C_WET], fm, c[C_FMSUM], c[C_FILM2L], rwet);
   T rso, rdo, rsd, rdd;
   canopy_soil<T>(cp, core, rwet, rso, rdo, rsd, rdd);
-  T* g = G + i * 4;
-  g[0] = rso; g[1] = rdo; g[2] = rsd; g[3] = rdd;
+  T* g = G + (int64_t)q * 4 * Bp + s;
+  g[0] = rso; g[Bp] = rdo; g[2 * Bp] = rsd; g[3 * Bp] = rdd;
+  if (gsoil) gsoil[(int64_t)q * Bp + s] = rwet;
 }
 
 // batch-mean canopy spectra from the per-chunk band sums: out (4, 2162) = mean over samples of rso, rdo, rsd, rdd
@@ -341,9 +393,9 @@ __global__ __launch_bounds__(256) void k_bandmean(const T* __restrict__ bandsum,
 // for k_prospect<double> (float64 ops take SGPR operands at no extra cost, the extra VGPRs are not free) and k_sailh
 // (its per-band input loads already overlap the scalar loads).
 template <typename T, bool STAGE, typename F>
-__device__ __forceinline__ void for_samples_staged(const T* __restrict__ cst, int64_t s0, int64_t s1, F&& body) {
+__device__ __forceinline__ void for_samples_staged(const T* __restrict__ cst, int64_t Bp, int64_t s0, int64_t s1, F&& body) {
   if (!STAGE) {
-    for (int64_t s = s0; s < s1; ++s) body(s, cst + s * NCONST);
+    for (int64_t s = s0; s < s1; ++s) body(s, ConstCol<T>{cst + s, Bp});
     return;
   }
   constexpr int SUB = 32;
@@ -351,7 +403,7 @@ __device__ __forceinline__ void for_samples_staged(const T* __restrict__ cst, in
   for (int64_t sb = s0; sb < s1; sb += SUB) {
     const int nsub = (int)((s1 - sb < SUB) ? (s1 - sb) : SUB);
     __syncthreads();                                   // the previous sub-chunk has been consumed by every wave
-    for (int i = threadIdx.x; i < nsub * NCONST; i += TILE) lds_c[i] = cst[sb * NCONST + i];
+    stage_constants<T>(lds_c, cst + sb, Bp, nsub);
     __syncthreads();
     for (int si = 0; si < nsub; ++si) body(sb + si, (const T*)(lds_c + si * NCONST));
   }
@@ -360,7 +412,7 @@ __device__ __forceinline__ void for_samples_staged(const T* __restrict__ cst, in
 // ------------------------------------------------------------------------------------------
 // standalone PROSPECT-5D / PRO: (B,2001) spectra out
 template <typename T>
-__global__ __launch_bounds__(TILE) void k_prospect(const T* __restrict__ tab, const T* __restrict__ cst, int64_t B,
+__global__ __launch_bounds__(TILE) void k_prospect(const T* __restrict__ tab, const T* __restrict__ cst, int64_t Bp, int64_t B,
                                                    int chunk, int po, T* __restrict__ o_refl,
                                                    T* __restrict__ o_tran, T* __restrict__ o_kchl) {
   int tile;
@@ -377,7 +429,7 @@ __global__ __launch_bounds__(TILE) void k_prospect(const T* __restrict__ tab, co
   if (o_refl) o_refl += s0 * po;
   if (o_tran) o_tran += s0 * po;
   if (o_kchl) o_kchl += s0 * po;
-  for_samples_staged<T, sizeof(T) == 4>(cst, s0, s1, [&](int64_t, const T* c) {
+  for_samples_staged<T, sizeof(T) == 4>(cst, Bp, s0, s1, [&](int64_t, auto c) {
     T refl, tran, absb, K;
     leaf_band<T>(tb, c[C_CAB], c[C_CCA], c[C_CDM], c[C_CW], c[C_CS], c[C_CANT], c[C_CBC], c[C_PROT], c[C_NM1], refl,
                  tran, absb, K);
@@ -392,7 +444,7 @@ __global__ __launch_bounds__(TILE) void k_prospect(const T* __restrict__ tab, co
 
 // standalone BSM: (B,2001) wet and dry soil spectra; optional user dry spectra (bsm.py:42-43)
 template <typename T>
-__global__ __launch_bounds__(TILE) void k_bsm(const T* __restrict__ tab, const T* __restrict__ cst, int64_t B,
+__global__ __launch_bounds__(TILE) void k_bsm(const T* __restrict__ tab, const T* __restrict__ cst, int64_t Bp, int64_t B,
                                               int chunk, int po, const T* __restrict__ rdry_in,
                                               T* __restrict__ o_refl, T* __restrict__ o_dry) {
   int tile;
@@ -407,7 +459,7 @@ __global__ __launch_bounds__(TILE) void k_bsm(const T* __restrict__ tab, const T
   unsigned off = (unsigned)band * (unsigned)sizeof(T);
   if (o_refl) o_refl += s0 * po;
   if (o_dry) o_dry += s0 * po;
-  for_samples_staged<T, true>(cst, s0, s1, [&](int64_t s, const T* c) {
+  for_samples_staged<T, true>(cst, Bp, s0, s1, [&](int64_t s, auto c) {
     T rdry = rdry_in ? (active ? rdry_in[s * po + band] : T(0)) : soil_dry<T>(tb, c[C_F1], c[C_F2], c[C_F3]);
     T fm[7] = {c[C_FM0], c[C_FM1], c[C_FM2], c[C_FM3], c[C_FM4], c[C_FM5], c[C_FM6]};
     T rwet;
@@ -422,7 +474,7 @@ __global__ __launch_bounds__(TILE) void k_bsm(const T* __restrict__ tab, const T
 
 // standalone SAILH: leaf / soil spectra in, four canopy reflectance spectra out, all (B,2162)
 template <typename T>
-__global__ __launch_bounds__(TILE) void k_sailh(const T* __restrict__ cst, int64_t B, int chunk, int pf,
+__global__ __launch_bounds__(TILE) void k_sailh(const T* __restrict__ cst, int64_t Bp, int64_t B, int chunk, int pf,
                                                 const T* __restrict__ i_rho, const T* __restrict__ i_tau,
                                                 const T* __restrict__ i_rs, T* __restrict__ o_rso,
                                                 T* __restrict__ o_rdo, T* __restrict__ o_rsd, T* __restrict__ o_rdd) {
@@ -436,11 +488,11 @@ __global__ __launch_bounds__(TILE) void k_sailh(const T* __restrict__ cst, int64
   unsigned off = (unsigned)(active ? band : 0) * (unsigned)sizeof(T);
   i_rho += s0 * pf; i_tau += s0 * pf; i_rs += s0 * pf;
   o_rso += s0 * pf; o_rdo += s0 * pf; o_rsd += s0 * pf; o_rdd += s0 * pf;
-  for_samples_staged<T, false>(cst, s0, s1, [&](int64_t, const T* c) {
+  for_samples_staged<T, false>(cst, Bp, s0, s1, [&](int64_t, auto c) {
     const T rho = *reinterpret_cast<const T*>(reinterpret_cast<const char*>(i_rho) + off);
     const T tau = *reinterpret_cast<const T*>(reinterpret_cast<const char*>(i_tau) + off);
     const T rs = *reinterpret_cast<const T*>(reinterpret_cast<const char*>(i_rs) + off);
-    const CanopyPar<T> cp = load_canopy(c);
+    const CanopyPar<T> cp = load_canopy<T>(c);
     T rso, rdo, rsd, rdd;
     canopy_band<T>(cp, rho, tau, T(1) - rho - tau, rs, rso, rdo, rsd, rdd);
     if (active) {
@@ -466,10 +518,19 @@ struct SensorTab {
 // j = w, w + nwave, ... so that the band index -- and with it the 48 SMAC coefficients, the interpolation
 // slots and the "is this gas absent in this band" tests -- is wave-uniform (scalar loads, scalar branches).
 // Results are staged in LDS and written out as whole (64 x nb) row blocks, coalesced.
-template <typename T>
-__global__ __launch_bounds__(1024) void k_sensor(SensorTab st, const T* __restrict__ G, const double* __restrict__ atm,
-                                                 int64_t B, T* __restrict__ R_TOC, T* __restrict__ R_TOA,
-                                                 T* __restrict__ L_TOA, const T* __restrict__ gsoil,
+// Element strides of the G rows, G[slot * slot + q * comp + s * sample] (q = rso, rdo, rsd, rdd), and of the rsoil
+// slots gsoil[slot * gs_slot + s * gs_sample]: k_bands (band on lanes) writes them sample-major, (B, nslot, 4) and
+// (B, nslot); k_slots (sample on lanes) writes structure-of-arrays, [nslot][4][Bp] and [nslot][Bp].
+struct GLayout {
+  int64_t slot, comp, sample, gs_slot, gs_sample;
+};
+
+// TG: element type of the G rows / gsoil values (double in the default float32 mode, see k_slots).  atm is
+// structure-of-arrays with pitch Bp.
+template <typename T, typename TG>
+__global__ __launch_bounds__(1024) void k_sensor(SensorTab st, const TG* __restrict__ G, GLayout gl,
+                                                 const double* __restrict__ atm, int64_t Bp, int64_t B, T* __restrict__ R_TOC, T* __restrict__ R_TOA,
+                                                 T* __restrict__ L_TOA, const TG* __restrict__ gsoil,
                                                  T* __restrict__ o_rsoil, T* __restrict__ o_La) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* stage = reinterpret_cast<T*>(smem_raw);          // [narr][64 * nb]
@@ -483,17 +544,17 @@ __global__ __launch_bounds__(1024) void k_sensor(SensorTab st, const T* __restri
   const int64_t sc = ok ? s : B - 1;
   double a[NATM];
 #pragma unroll
-  for (int i = 0; i < NATM; ++i) a[i] = atm[sc * NATM + i];
+  for (int i = 0; i < NATM; ++i) a[i] = atm[i * Bp + sc];
   const int tile = 64 * nb;
   for (int j = wave; j < nb; j += nwave) {
     const int sl0 = st.slot0[j], sl1 = st.slot1[j];
     const double f = st.frac[j];
-    const T* g0 = G + (sc * st.nslot + sl0) * 4;
-    const T* g1 = G + (sc * st.nslot + sl1) * 4;
+    const TG* g0 = G + sl0 * gl.slot + sc * gl.sample;
+    const TG* g1 = G + sl1 * gl.slot + sc * gl.sample;
     double v[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      double y0 = (double)g0[q], y1 = (double)g1[q];
+      double y0 = (double)g0[q * gl.comp], y1 = (double)g1[q * gl.comp];
       v[q] = y0 + (y1 - y0) * f;                     // np.interp (SPART.py:220-223)
     }
     SmacOut so = smac_band(a, st.coef + j, nb);
@@ -506,7 +567,7 @@ __global__ __launch_bounds__(1024) void k_sensor(SensorTab st, const T* __restri
     stage[2 * tile + o] = (T)ltoa;
     int na = 3;
     if (o_rsoil && gsoil) {
-      double y0 = (double)gsoil[sc * st.nslot + sl0], y1 = (double)gsoil[sc * st.nslot + sl1];
+      double y0 = (double)gsoil[sl0 * gl.gs_slot + sc * gl.gs_sample], y1 = (double)gsoil[sl1 * gl.gs_slot + sc * gl.gs_sample];
       stage[na * tile + o] = (T)(y0 + (y1 - y0) * f);
       ++na;
     }
@@ -534,12 +595,15 @@ struct Out9 {
   double* o[9];
 };
 __global__ __launch_bounds__(256) void k_smac(const double* __restrict__ coef, int nb, const double* __restrict__ atm,
-                                              int64_t B, Out9 out) {
+                                              int64_t Bp, int64_t B, Out9 out) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * nb) return;
   int64_t s = i / nb;
   int j = (int)(i - s * nb);
-  SmacOut so = smac_band(atm + s * NATM, coef + j, nb);
+  double a[NATM];
+#pragma unroll
+  for (int q = 0; q < NATM; ++q) a[q] = atm[q * Bp + s];
+  SmacOut so = smac_band(a, coef + j, nb);
   out.o[0][i] = so.Ta_s; out.o[1][i] = so.Ta_o; out.o[2][i] = so.Tg; out.o[3][i] = so.Ra_dd; out.o[4][i] = so.Ra_so;
   out.o[5][i] = so.Ta_ss; out.o[6][i] = so.Ta_sd; out.o[7][i] = so.Ta_oo; out.o[8][i] = so.Ta_do;
 }

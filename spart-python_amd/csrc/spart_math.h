@@ -691,6 +691,49 @@ SPART_HD double lidf_theta(int i) { return (i < 8) ? 10.0 * (i + 1) : 80.0 + 2.0
 // litab: 5,15,...,75,81,83,...,89                                  (sailh.py:49)
 SPART_HD double lidf_litab(int i) { return (i < 8) ? 5.0 + 10.0 * i : 81.0 + 2.0 * (i - 8); }
 
+// The literal iteration again (the reference's stopping rule and iterates), but in the small unknown u = x - 2 theta:
+//   x <- x + 1/2 (y - x + 2 theta)   ==   u <- u + 1/2 (y - u),   y = sin x (a + b cos x),
+// with sin x, cos x from the angle-addition formulas with the tabulated (sin, cos)(2 theta) and the Taylor polynomials
+// of sin u, cos u (to u^19 / u^18; |u| <= |a| + |b|/2 <= 1: 1/21! = 2e-20), i.e. ~30 multiply-adds per step instead
+// of a library sincos with its argument reduction.  The iterates differ from the x-form's by rounding (1e-16) only.
+// |a| + |b|/2 > 1 (non-physical) and a > 1 keep the library form.
+SPART_HD double lidf_dcum_lit(double a, double b, int i) {
+  if (!(::fabs(a) + 0.5 * ::fabs(b) <= 1.0)) return lidf_dcum(a, b, lidf_theta(i));
+  const double rd = PI / 180.0;
+  const double theta2 = 2.0 * rd * lidf_theta(i);
+  const double s2 = lidf_sin_2theta(i), c2 = lidf_cos_2theta(i);
+  double u = 0.0, y, dx;
+  int it = 0;
+  do {  // sailh.py:378-382
+    const double u2 = u * u;
+    double ps = -1.0 / 121645100408832000.0;            // sin u / u:  ... - u^18/19!
+    ps = ps * u2 + 1.0 / 355687428096000.0;
+    ps = ps * u2 - 1.0 / 1307674368000.0;
+    ps = ps * u2 + 1.0 / 6227020800.0;
+    ps = ps * u2 - 1.0 / 39916800.0;
+    ps = ps * u2 + 1.0 / 362880.0;
+    ps = ps * u2 - 1.0 / 5040.0;
+    ps = ps * u2 + 1.0 / 120.0;
+    ps = ps * u2 - 1.0 / 6.0;
+    ps = ps * u2 + 1.0;
+    double pc = 1.0 / 6402373705728000.0;                // (1 - cos u) / u^2:  1/2 - u^2/24 + ... + u^16/18!
+    pc = pc * u2 - 1.0 / 20922789888000.0;
+    pc = pc * u2 + 1.0 / 87178291200.0;
+    pc = pc * u2 - 1.0 / 479001600.0;
+    pc = pc * u2 + 1.0 / 3628800.0;
+    pc = pc * u2 - 1.0 / 40320.0;
+    pc = pc * u2 + 1.0 / 720.0;
+    pc = pc * u2 - 1.0 / 24.0;
+    pc = pc * u2 + 0.5;
+    const double su = u * ps, cu = 1.0 - u2 * pc;
+    const double sn = s2 * cu + c2 * su, cs = c2 * cu - s2 * su;   // sin x, cos x
+    y = sn * (a + b * cs);
+    dx = 0.5 * (y - u);
+    u += dx;
+  } while (::fabs(dx) > 1e-8 && ++it < 100000);
+  return (2.0 * y + theta2) / PI;
+}
+
 // sin / cos of the 13 class-centre inclinations litab(i) and of twice the 12 class boundaries theta(i): constants of
 // the model (sailh.py:49, 388-394), tabulated (math.sin / math.cos of the same double arguments) so that no sample
 // pays for 38 library calls on them
@@ -715,7 +758,7 @@ SPART_HD double lidf_cos_2theta(int i) {
 SPART_HD void leaf_angles(double a, double b, double lidf[NLINCL]) {
   double prev = 0.0;
   for (int i = 0; i < NLINCL; ++i) {
-    double F = (i < NLINCL - 1) ? lidf_dcum(a, b, lidf_theta(i)) : 1.0;
+    double F = (i < NLINCL - 1) ? lidf_dcum_lit(a, b, i) : 1.0;
     lidf[i] = F - prev;
     prev = F;
   }
@@ -838,40 +881,41 @@ enum PreludeMask { PRE_LEAF = 1, PRE_SOIL = 2, PRE_CANOPY = 4, PRE_ATM = 8, PRE_
 
 // FAST (used for T = float, tolerance 1e-4): Newton LIDF and the 8-point hot-spot rule, both ~1e-7 from
 // the literal forms; T = double keeps the reference's iteration and the 16-point rule.
-template <typename T, bool FAST = false>
-SPART_HD void sample_prelude(const double* p /*[27]*/, double rho_th, double tau_th, int mask, T* cst /*[NCONST]*/,
-                             double* atm /*[NATM]*/, double* lidf_out /*[13]*/) {
+// Results leave through `out` as soon as they exist -- out.c(ConstIdx, v), out.a(AtmIdx, v), out.l(i, lidf_i) -- so
+// that a kernel can store them straight to memory instead of holding 64 float64 values in registers across the
+// LIDF iteration and the hot-spot quadrature (k_prelude: 262 -> fewer VGPRs, two waves per SIMD instead of one).
+// Groups excluded by `mask` are not written at all.
+template <bool FAST, typename In, typename Out>
+SPART_HD void sample_prelude_to(const In& in /* in(i) = parameter i of 27, read when first needed */, double rho_th,
+                                double tau_th, int mask, Out& out) {
   SPART_NO_CONTRACT
   const double d2r = PI / 180.0;
-  for (int i = 0; i < NCONST; ++i) cst[i] = T(0);
-  for (int i = 0; i < NATM; ++i) atm[i] = 0.0;
-  for (int i = 0; i < NLINCL; ++i) lidf_out[i] = 0.0;
   if (mask & PRE_LEAF) {
   // ---- leaf (prospect_5d.py:135-155, 170-179)
-  double Cab = p[0], Cdm = p[1], Cw = p[2], Cs = p[3], Cca = p[4], Cant = p[5], N = p[6], PROT = p[7], CBC = p[8];
+  double Cab = in(0), Cdm = in(1), Cw = in(2), Cs = in(3), Cca = in(4), Cant = in(5), N = in(6), PROT = in(7), CBC = in(8);
   if ((PROT > 0.0 || CBC > 0.0) && Cdm > 0.0) Cdm = 0.0;  // PROSPECT-PRO rule (:148-155)
   double iN = 1.0 / N;
-  cst[C_CAB] = T(Cab * iN);
-  cst[C_CCA] = T(Cca * iN);
-  cst[C_CDM] = T(Cdm * iN);
-  cst[C_CW] = T(Cw * iN);
-  cst[C_CS] = T(Cs * iN);
-  cst[C_CANT] = T(Cant * iN);
-  cst[C_CBC] = T(CBC * iN);
-  cst[C_PROT] = T(PROT * iN);
-  cst[C_NM1] = T(N - 1.0);
-  cst[C_RHO_TH] = T(rho_th);
-  cst[C_TAU_TH] = T(tau_th);
+  out.c(C_CAB, Cab * iN);
+  out.c(C_CCA, Cca * iN);
+  out.c(C_CDM, Cdm * iN);
+  out.c(C_CW, Cw * iN);
+  out.c(C_CS, Cs * iN);
+  out.c(C_CANT, Cant * iN);
+  out.c(C_CBC, CBC * iN);
+  out.c(C_PROT, PROT * iN);
+  out.c(C_NM1, N - 1.0);
+  out.c(C_RHO_TH, rho_th);
+  out.c(C_TAU_TH, tau_th);
   }
   if (mask & PRE_SOIL) {
   // ---- soil (bsm.py:49-52, 99-103, 121)
-  double Bs = p[9], lat = p[10], lon = p[11], SMp = p[12], SMC = p[13], film = p[14];
-  cst[C_F1] = T(Bs * ::sin(lat * d2r));
-  cst[C_F2] = T(Bs * ::cos(lat * d2r) * ::sin(lon * d2r));
-  cst[C_F3] = T(Bs * ::cos(lat * d2r) * ::cos(lon * d2r));
+  double Bs = in(9), lat = in(10), lon = in(11), SMp = in(12), SMC = in(13), film = in(14);
+  out.c(C_F1, Bs * ::sin(lat * d2r));
+  out.c(C_F2, Bs * ::cos(lat * d2r) * ::sin(lon * d2r));
+  out.c(C_F3, Bs * ::cos(lat * d2r) * ::cos(lon * d2r));
   double mu = (SMp - 5.0) / SMC;
   bool wet = mu > 0.0;
-  cst[C_WET] = T(wet ? 1.0 : 0.0);
+  out.c(C_WET, wet ? 1.0 : 0.0);
   {
     double e = wet ? ::exp(-mu) : 1.0, pw = 1.0, fact = 1.0, fsum = 0.0;
     for (int k = 0; k < 7; ++k) {  // poisson.pmf(k, mu) = e^-mu mu^k / k!
@@ -880,18 +924,18 @@ SPART_HD void sample_prelude(const double* p /*[27]*/, double rho_th, double tau
         fact *= k;
       }
       double f = wet ? e * pw / fact : (k == 0 ? 1.0 : 0.0);
-      cst[C_FM0 + k] = T(f);
+      out.c(C_FM0 + k, f);
       if (k > 0) fsum += f;
     }
-    cst[C_FMSUM] = T(fsum);
+    out.c(C_FMSUM, fsum);
   }
-  cst[C_FILM2] = T(2.0 * film);
-  cst[C_FILM2L] = T(2.0 * film * 1.4426950408889634);
+  out.c(C_FILM2, 2.0 * film);
+  out.c(C_FILM2L, 2.0 * film * 1.4426950408889634);
   }
-  double tts = p[19], tto = p[20], rel = p[21];
+  double tts = in(19), tto = in(20), rel = in(21);
   if (mask & PRE_CANOPY) {
   // ---- canopy geometry (sailh.py:46-105)
-  double LAI = p[15], LIDFa = p[16], LIDFb = p[17], q = p[18];
+  double LAI = in(15), LIDFa = in(16), LIDFb = in(17), q = in(18);
   double psi = ::fabs(rel - 360.0 * ::rint(rel / 360.0));  // :65 (Python round = half-to-even = rint)
   double psi_rad = psi * d2r;
   double sin_tts = ::sin(tts * d2r), cos_tts = ::cos(tts * d2r), tan_tts = ::tan(tts * d2r);
@@ -902,11 +946,11 @@ SPART_HD void sample_prelude(const double* p /*[27]*/, double rho_th, double tau
   double ks = 0, ko = 0, bf = 0, sob = 0, sof = 0, Fprev = 0;
   for (int i = 0; i < NLINCL; ++i) {
     double F = (i < NLINCL - 1) ? (FAST ? lidf_dcum_newton(LIDFa, LIDFb, i)
-                                        : lidf_dcum(LIDFa, LIDFb, lidf_theta(i)))
+                                        : lidf_dcum_lit(LIDFa, LIDFb, i))
                                 : 1.0;
     double li = F - Fprev;
     Fprev = F;
-    lidf_out[i] = li;
+    out.l(i, li);
     double sl = lidf_sin_litab(i), cl = lidf_cos_litab(i);   // sin / cos of litab(i), sailh.py:81
     double chi_s, chi_o, frho, ftau;
     volscatt1(sin_tts, cos_tts, sin_tto, cos_tto, psi_rad, sin_psi, cos_psi, sl, cl, chi_s, chi_o, frho, ftau);  // :81-83
@@ -916,58 +960,78 @@ SPART_HD void sample_prelude(const double* p /*[27]*/, double rho_th, double tau
     sob += frho * PI / (cos_tts * cos_tto) * li;                                              // :88, 96
     sof += ftau * PI / (cos_tts * cos_tto) * li;                                              // :89, 97
   }
-  cst[C_SDB] = T(0.5 * (ks + bf));  // :100-105
-  cst[C_SDF] = T(0.5 * (ks - bf));
-  cst[C_DDB] = T(0.5 * (1.0 + bf));
-  cst[C_DDF] = T(0.5 * (1.0 - bf));
-  cst[C_DOB] = T(0.5 * (ko + bf));
-  cst[C_DOF] = T(0.5 * (ko - bf));
-  cst[C_SOB] = T(sob);
-  cst[C_SOF] = T(sof);
-  cst[C_BF] = T(bf);
-  cst[C_HBF] = T(0.5 * bf);
-  cst[C_KS] = T(ks);
-  cst[C_KO] = T(ko);
-  cst[C_LAI] = T(LAI);
-  cst[C_LAI2] = T(LAI * 1.4426950408889634);
+  out.c(C_SDB, 0.5 * (ks + bf));  // :100-105
+  out.c(C_SDF, 0.5 * (ks - bf));
+  out.c(C_DDB, 0.5 * (1.0 + bf));
+  out.c(C_DDF, 0.5 * (1.0 - bf));
+  out.c(C_DOB, 0.5 * (ko + bf));
+  out.c(C_DOF, 0.5 * (ko - bf));
+  out.c(C_SOB, sob);
+  out.c(C_SOF, sof);
+  out.c(C_BF, bf);
+  out.c(C_HBF, 0.5 * bf);
+  out.c(C_KS, ks);
+  out.c(C_KO, ko);
+  out.c(C_LAI, LAI);
+  out.c(C_LAI2, LAI * 1.4426950408889634);
   double tss = ::exp(-ks * LAI), too = ::exp(-ko * LAI);  // :200-201
-  cst[C_TSS] = T(tss);
-  cst[C_TOO] = T(too);
-  cst[C_Z] = T((1.0 - tss * too) / (ko + ks));             // :203
+  out.c(C_TSS, tss);
+  out.c(C_TOO, too);
+  out.c(C_Z, (1.0 - tss * too) / (ko + ks));             // :203
   double ic, p2w;
   hotspot_integrals<FAST>(ko, ks, LAI, q, dso, ic, p2w);
-  cst[C_HOT] = T(ic * LAI);   // sum(Pso[0:60]) * iLAI  (:216)
-  cst[C_PSO2W] = T(p2w);      // Pso[60]               (:219)
+  out.c(C_HOT, ic * LAI);   // sum(Pso[0:60]) * iLAI  (:216)
+  out.c(C_PSO2W, p2w);      // Pso[60]               (:219)
   }
   if (mask & PRE_ATM) {
   // ---- atmosphere scalars (smac.py:94-102, 128-138) + ET factor (SPART.py:345-353)
-  double psi_s = p[21];  // SMAC uses rel_angle unfolded (smac.py:38)
-  double Pa = p[25];
+  double psi_s = in(21);  // SMAC uses rel_angle unfolded (smac.py:38)
+  double Pa = in(25);
   const double cdr = PI / 180.0, crd = 180.0 / PI;
   double us = ::cos(tts * cdr), uv = ::cos(tto * cdr);
   double cksi = -((us * uv) + (::sqrt(1.0 - us * us) * ::sqrt(1.0 - uv * uv) * ::cos(psi_s * crd)));  // sic (:130)
   if (cksi < -1.0) cksi = -1.0;                                                                        // :134-135
-  atm[A_US] = us;
-  atm[A_UV] = uv;
-  atm[A_M] = 1.0 / us + 1.0 / uv;
-  atm[A_PEQ] = Pa / 1013.25;
-  atm[A_PA] = Pa;
-  atm[A_AOT] = p[22];
-  atm[A_UO3] = p[23];
-  atm[A_UH2O] = p[24];
-  atm[A_CKSI] = cksi;
-  atm[A_KSID] = crd * ::acos(cksi);
-  atm[A_LOGPEQ] = ::log(atm[A_PEQ]);
-  atm[A_LOGM] = ::log(atm[A_M]);
-  atm[A_LOGO3M] = ::log(p[23] * atm[A_M]);
-  atm[A_LOGH2OM] = ::log(p[24] * atm[A_M]);
-  double b = 2.0 * PI * p[26] / 365.0;
+  const double am = 1.0 / us + 1.0 / uv, peq = Pa / 1013.25;
+  out.a(A_US, us);
+  out.a(A_UV, uv);
+  out.a(A_M, am);
+  out.a(A_PEQ, peq);
+  out.a(A_PA, Pa);
+  out.a(A_AOT, in(22));
+  out.a(A_UO3, in(23));
+  out.a(A_UH2O, in(24));
+  out.a(A_CKSI, cksi);
+  out.a(A_KSID, crd * ::acos(cksi));
+  out.a(A_LOGPEQ, ::log(peq));
+  out.a(A_LOGM, ::log(am));
+  out.a(A_LOGO3M, ::log(in(23) * am));
+  out.a(A_LOGH2OM, ::log(in(24) * am));
+  double b = 2.0 * PI * in(26) / 365.0;
   double sb, cb;
   ::sincos(b, &sb, &cb);                                    // cos 2b, sin 2b by the double-angle formulas; cos(tts) = us:
   double corr = 1.00011 + 0.034221 * cb + 0.00128 * sb + 0.000719 * (cb * cb - sb * sb) +   // three library calls less,
                 0.000077 * (2.0 * sb * cb);                                                 // 1e-16 from the literal form
-  atm[A_LAF] = corr * us / PI;                              // SPART.py:345-353 (cos(tts pi/180) there)
+  out.a(A_LAF, corr * us / PI);                             // SPART.py:345-353 (cos(tts pi/180) there)
   }
+}
+
+// the same into plain arrays (tests/hostmath): unwritten entries are zero
+template <typename T> struct PreludeArrays {
+  T* cst;
+  double* atm;
+  double* lidf;
+  SPART_HD void c(int i, double v) { cst[i] = T(v); }
+  SPART_HD void a(int i, double v) { atm[i] = v; }
+  SPART_HD void l(int i, double v) { lidf[i] = v; }
+};
+template <typename T, bool FAST = false>
+SPART_HD void sample_prelude(const double* p /*[27]*/, double rho_th, double tau_th, int mask, T* cst /*[NCONST]*/,
+                             double* atm /*[NATM]*/, double* lidf_out /*[13]*/) {
+  for (int i = 0; i < NCONST; ++i) cst[i] = T(0);
+  for (int i = 0; i < NATM; ++i) atm[i] = 0.0;
+  for (int i = 0; i < NLINCL; ++i) lidf_out[i] = 0.0;
+  PreludeArrays<T> out{cst, atm, lidf_out};
+  sample_prelude_to<FAST>([p](int i) { return p[i]; }, rho_th, tau_th, mask, out);
 }
 
 // ------------------------------------------------------------------------------------------

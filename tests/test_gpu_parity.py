@@ -14,6 +14,8 @@ TOL = {"float64": 1e-6, "float32": 1e-4}
 # spectra (1e-7 in fp64 = the reference's own assert_almost_equal precision and its E1-quadrature
 # noise; 1e-6 in fp32)
 FLOOR = {"float64": 0.1, "float32": 1e-2}
+# sensor columns R_TOC / R_TOA / L_TOA: SURVEY.md section 8(d)'s metric |x - ref| / max(|ref|, 1e-6), both dtypes
+COLFLOOR = 1e-6
 
 
 @pytest.fixture(scope="module")
@@ -104,7 +106,7 @@ def test_full_chain_golden(golden, dtype, torch_mod):
         P = torch_mod.as_tensor(g[name + "/P"].T.copy(), device="cuda:0")
         out = eng.run(P, dtype, materialize=("rsoil", "La"))
         for k in ("R_TOC", "R_TOA", "L_TOA", "rsoil", "La"):
-            e = rel_err(out[k].cpu().numpy(), g[f"{name}/{k}"], 1e-3)
+            e = rel_err(out[k].cpu().numpy(), g[f"{name}/{k}"], COLFLOOR)
             worst[(name, k)] = e
             assert e < TOL[dtype], (name, k, e)
     print({k: f"{v:.1e}" for k, v in worst.items() if v > 0.1 * TOL[dtype]})
@@ -125,7 +127,7 @@ def test_full_chain_vs_oracle_spectra(oracle, tables, dtype, torch_mod):
     for k in fields:
         assert rel_err(out[k].cpu().numpy(), expect[k], FLOOR[dtype]) < TOL[dtype], k
     for k in ("R_TOC", "R_TOA", "L_TOA"):
-        assert rel_err(out[k].cpu().numpy(), ref[k], 1e-3) < TOL[dtype], k
+        assert rel_err(out[k].cpu().numpy(), ref[k], COLFLOOR) < TOL[dtype], k
 
 
 def test_ragged_and_edge_batches(oracle, tables, torch_mod):
@@ -137,7 +139,7 @@ def test_ragged_and_edge_batches(oracle, tables, torch_mod):
         ref = oracle.spart_run(P, "Sentinel2A-MSI", tables, pso="gl")
         out = eng.run(torch_mod.as_tensor(P.T.copy(), device="cuda:0"), "float64")
         for k in ("R_TOC", "R_TOA", "L_TOA"):
-            assert rel_err(out[k].cpu().numpy(), ref[k], 1e-3) < 1e-6
+            assert rel_err(out[k].cpu().numpy(), ref[k], COLFLOOR) < 1e-6
     out = eng.run(torch_mod.zeros((27, 0), dtype=torch_mod.float64, device="cuda:0"), "float32")
     assert out["R_TOC"].shape == (0, 13)
 
@@ -145,7 +147,8 @@ def test_ragged_and_edge_batches(oracle, tables, torch_mod):
 def test_full_size_properties(torch_mod):
     """BASELINE size (1M spectra, config-4 workload): size-independent checks.
     (1) every fp32 column entry against the fp64 evaluation of the SAME 1M rows (fp64 itself is pinned to
-        the oracle / reference by the tests above): max |d| / max(|ref|, 1e-3) < 1e-4 over all 13M entries;
+        the oracle / reference by the tests above): max |d| / max(|ref|, 1e-6) < 1e-4 over all 13M entries
+        (test_float32_tolerance_at_size below does the same for config 5 and for the legacy float32 columns);
     (2) evaluating the batch in two ragged halves gives bit-identical columns (samples are independent);
     (3) batch-mean spectra (all 2162 bands of all samples) agree between fp32 and fp64."""
     from spart_amd import get_engine, workloads
@@ -156,7 +159,7 @@ def test_full_size_properties(torch_mod):
     out = {k: v.clone() for k, v in eng.run(P, "float32", materialize=("band_mean",)).items()}
     for k in ("R_TOC", "R_TOA", "L_TOA"):
         assert torch_mod.isfinite(out[k]).all()
-        err = ((out[k].double() - o64[k]).abs() / o64[k].abs().clamp_min(1e-3)).max().item()
+        err = ((out[k].double() - o64[k]).abs() / o64[k].abs().clamp_min(COLFLOOR)).max().item()
         assert err < 1e-4, (k, err)
     bm_err = ((out["band_mean"].double() - o64["band_mean"]).abs() / o64["band_mean"].abs().clamp_min(1e-3)).max().item()
     assert bm_err < 1e-4, bm_err
@@ -165,6 +168,67 @@ def test_full_size_properties(torch_mod):
     o2 = eng.run(P[:, h:].contiguous(), "float32")
     for k in ("R_TOC", "R_TOA", "L_TOA"):
         assert torch_mod.equal(torch_mod.cat([o1[k], o2[k]]), out[k])
+
+
+@pytest.mark.parametrize("kind,sensor", [("full", "Sentinel2A-MSI"), ("pro", "Sentinel2B-MSI")])
+def test_float32_tolerance_at_size(kind, sensor, torch_mod):
+    """BASELINE configs 4 (22-D LHS, Sentinel-2A) and 5 (PROSPECT-PRO, Cdm = 0, Sentinel-2B) at B = 1M, float32 mode
+    against the float64 mode of the same rows, on SURVEY.md section 8(d)'s metric |x - ref| / max(|ref|, 1e-6):
+
+    * default float32 mode (sensor-slot bands re-evaluated in float64, spart_materialize.f32_columns = 0): EVERY one of
+      the 3 x 13M entries is within 1e-4 -- in fact within float32 rounding (1e-7) of the float64 value, physical or not;
+    * legacy float32 columns (f32_columns = 1): counted, not hidden -- the entries over 1e-4 are reported by number
+      (entries and samples) and bounded: they are the nearly conservative leaves on which the reference's own canopy
+      formulas cancel (sailh.py:185-214), which is why that mode is an opt-in."""
+    from spart_amd import get_engine, workloads
+    eng = get_engine(sensor, 0)
+    B = 1_000_000
+    P = torch_mod.as_tensor(workloads.lhs_params(B, kind).T.copy(), device="cuda:0")
+    o64 = {k: v.clone() for k, v in eng.run(P, "float64").items()}
+    o32 = {k: v.clone() for k, v in eng.run(P, "float32").items()}
+    leg = eng.run(P, "float32", f32_columns=True)
+    report = {}
+    for k in ("R_TOC", "R_TOA", "L_TOA"):
+        ref = o64[k]
+        assert torch_mod.isfinite(ref).all() and torch_mod.isfinite(o32[k]).all()
+        den = ref.abs().clamp_min(COLFLOOR)
+        err = ((o32[k].double() - ref).abs() / den).max().item()
+        assert err < 1e-4, (kind, k, err)
+        assert err < 2e-7, (kind, k, err)                  # one float32 rounding of the float64 value
+        el = (leg[k].double() - ref).abs() / den
+        bad = el > 1e-4
+        nbad, nrow = int(bad.sum().item()), int(bad.any(dim=1).sum().item())
+        report[k] = (err, float(el.max().item()), nbad, nrow)
+        assert nbad < 1000 and nrow < 500, (kind, k, nbad, nrow)     # of 13M entries / 1M samples (measured: 175 in 174 samples)
+    print(kind, {k: f"default max {v[0]:.1e} | f32_columns max {v[1]:.1e}, {v[2]} entries in {v[3]} samples > 1e-4"
+                 for k, v in report.items()})
+
+
+def test_float32_columns_are_the_float64_columns_rounded(golden, torch_mod):
+    """The default float32 mode takes its sensor columns from a float64 evaluation of the sensor-slot bands over the
+    float64 prelude (k_bands_pruned<double>): on every sensor (integer and fractional band centres), with debug rsoil
+    and with user dry-soil spectra, they equal the float64 mode's columns converted to float32."""
+    from spart_amd import get_engine, workloads
+    for sensor, kind in (("Sentinel2A-MSI", "full"), ("Sentinel2B-MSI", "pro"), ("TerraAqua-MODIS", "full"),
+                         ("LANDSAT7-ETM", "pro"), ("Sentinel3A-OLCI", "full")):
+        eng = get_engine(sensor, 0)
+        P = torch_mod.as_tensor(workloads.lhs_params(3001, kind, seed=77).T.copy(), device="cuda:0")
+        o64 = {k: v.clone() for k, v in eng.run(P, "float64", materialize=("rsoil", "La")).items()}
+        for kw in (dict(), dict(prune=True), dict(materialize=("rso", "leaf_refl"))):
+            mat = tuple(kw.pop("materialize", ())) + ("rsoil", "La")
+            o32 = eng.run(P, "float32", materialize=mat, **kw)
+            for k in ("R_TOC", "R_TOA", "L_TOA", "rsoil", "La"):
+                d = (o32[k].double() - o64[k]).abs() / o64[k].abs().clamp_min(1e-30)
+                assert float(d.max()) < 1.2e-7, (sensor, kw, k, float(d.max()))
+    eng = get_engine("Sentinel2A-MSI", 0)
+    g = golden["rdry"]
+    P = workloads.lhs_params(3, "full", seed=1)
+    cols = [P[:, j] for j in range(27)]
+    cols[9] = cols[10] = cols[11] = None
+    a = eng.run(cols, "float64", rdry=g["spectra"])
+    b = eng.run(cols, "float32", rdry=g["spectra"].astype(np.float32))
+    for k in ("R_TOC", "R_TOA", "L_TOA"):
+        assert float(((b[k].double() - a[k]).abs() / a[k].abs()).max()) < 1e-6, k     # (the spectra themselves were rounded)
 
 
 def test_reference_style_api(golden, torch_mod, capsys):
@@ -181,7 +245,7 @@ def test_reference_style_api(golden, torch_mod, capsys):
     assert abs(df["R_TOA"].iloc[0] / 0.0497552219811317 - 1) < 1e-6
     assert abs(df["L_TOA"].iloc[0] / 0.022812529362725764 - 1) < 1e-6
     g = golden["e2e"]
-    assert rel_err(df["R_TOA"].to_numpy(), g["readme/TerraAqua-MODIS/R_TOA"][0], 1e-3) < 1e-6
+    assert rel_err(df["R_TOA"].to_numpy(), g["readme/TerraAqua-MODIS/R_TOA"][0], COLFLOOR) < 1e-6
     # PROSPECT-PRO warning text goes to stdout once (prospect_5d.py:148-155)
     pro = SPART.LeafBiology(40, 0.01, 0.02, 0, 10, 10, 1.5, PROT=0.001, CBC=0.009)
     df2 = SPART.SPART(SPART.SoilParameters(0.5, 0, 100, 20, 25, 0.015), pro, canopy,
@@ -265,7 +329,7 @@ def test_hot_spot_and_geometry_edges(oracle, tables, dtype, torch_mod):
         assert rel_err(out[k].cpu().numpy()[keep], e[keep], fl) < tol, k
         assert rel_err(out[k].cpu().numpy(), e, fl) < 10 * tol, k
     for k in ("R_TOC", "R_TOA", "L_TOA"):
-        assert rel_err(out[k].cpu().numpy(), ref[k], 1e-3) < tol, k
+        assert rel_err(out[k].cpu().numpy(), ref[k], COLFLOOR) < tol, k
 
 
 def test_nan_and_nonphysical_inputs_do_not_crash(torch_mod):
@@ -391,7 +455,7 @@ def test_user_dry_soil_spectra_full_chain(golden, dtype, torch_mod):
                          SPART.AtmosphericProperties(0.325, 0.35, 1.41, 1013.25), SPART.Angles(40, 0, 0), sensor, 100,
                          dtype=dtype).run(debug=True)
         for k in ("R_TOC", "R_TOA", "L_TOA", "rsoil"):
-            assert rel_err(df[k].to_numpy(), g[f"{i}/{k}"], 1e-3) < TOL[dtype], (i, k)
+            assert rel_err(df[k].to_numpy(), g[f"{i}/{k}"], COLFLOOR) < TOL[dtype], (i, k)
     # batched: per-sample spectra, GSV columns absent
     eng = get_engine("Sentinel2A-MSI", 0)
     P = workloads.lhs_params(3, "full", seed=1)
@@ -452,4 +516,4 @@ def test_edge_rows_golden(golden, torch_mod):
     phys = keep & np.all((g["R_TOC"] >= 0) & (g["R_TOC"] <= 1), axis=1)
     assert phys.sum() > 60
     for k in ("R_TOC", "R_TOA", "L_TOA"):
-        assert rel_err(o32[k].cpu().numpy()[phys], g[k][phys], 1e-3) < 1e-4, k
+        assert rel_err(o32[k].cpu().numpy()[phys], g[k][phys], COLFLOOR) < 1e-4, k
