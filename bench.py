@@ -1,17 +1,21 @@
-"""Headline benchmark: full SPART spectra/sec (R_TOC + R_TOA + L_TOA) at batch 1M per GPU.
+"""Headline benchmark: full SPART spectra/sec (R_TOC + R_TOA + L_TOA) at batch 1M (BASELINE.json config 4).
 
     python bench.py --gpus 1 --steps 10 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A step = one pass of the hot path (spart_run_batch: prelude + fused PROSPECT/BSM/SAILH band
-kernel over all 2162 bands + SMAC/TOC->TOA) over one batch of synthetic parameters already
-resident in HBM, plus -- for N > 1 -- the single RCCL gather of the (B, nb, 3) result shards to
-rank 0 (BASELINE.json north_star).  Workload = BASELINE config 4's generator (22-D Latin
-hypercube, Sentinel2A-MSI, fp32 bands / fp64 sample scalars) at B = 1,000,000 per GPU
-(weak scaling: every rank evaluates its own 1M-spectrum shard).  Rank 0 prints ONE JSON line.
+A step = one pass of the hot path (spart_run_batch: prelude + fused PROSPECT/BSM/SAILH band kernel over all 2162
+bands + float64 sensor-slot pass + SMAC/TOC->TOA) over one batch of synthetic parameters already resident in HBM,
+plus -- for N > 1 -- the single RCCL gather of the (3, B/N, nb) result shards to rank 0 (BASELINE.json north_star).
+Workload = config 4's generator (22-D Latin hypercube, Sentinel2A-MSI, float32 bands / float64 sample scalars).
+
+Scaling (--scaling): N > 1 defaults to STRONG -- the global batch of 1M spectra is cut into N contiguous shards
+(spart_amd.sharding.shard_bounds; 8 x 125k + gather = config 4 as BASELINE states it); `weak` gives every rank its own
+1M-spectrum shard.  Rank 0 prints ONE JSON line; at N = 1 it also carries driver-timed sub-records: "fp64" (the
+reference's own arithmetic) and "configs" (BASELINE configs 2, 3, 5 on one GPU).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -20,29 +24,42 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "spart-python_amd"))
 
-PROFILE_TAG = "r1_k"      # profiles/<tag>_traffic.json, <tag>_valu.json: the committed rocprofv3 PMC passes of this build
+PROFILE_TAG = "r2"        # profiles/<tag>_counters_<dtype>.json: the committed rocprofv3 PMC passes (tools/ingest_profiles.py)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-FP32_VALU_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector
+VALU_PEAK_TFLOPS = {"float32": 157.3, "float64": 78.6}   # MI355X_MICROARCH.md: peak FP32 / FP64 vector
+ISSUE_CYCLES = {"float32": 2.0, "float64": 4.0}          # cycles per wave64 VALU instruction on a SIMD-32 (fp64: half rate)
+FLOP_EQ_PER_SPECTRUM = 8.7e5                             # the reference's arithmetic per spectrum
+FLOP_EQ_PER_LEAF = 2001 * 160
+METRIC = "SPART spectra/sec (R_TOC+R_TOA+L_TOA) at batch 1M; achieved HBM GB/s vs peak"
 
 
 def algorithmic_bytes(nb, dtype):
-    """inputs + requested outputs per spectrum (inputs are always float64 here)."""
+    """inputs + requested outputs per spectrum (SURVEY.md section 8d counts 27 x 4 B of inputs = 264 B with 13 bands;
+    here the 27 inputs stay float64 -- SMAC's cos(psi * 180/pi) amplifies a float32 rounding of the azimuth 3283x --
+    hence 372 B)."""
     es = 4 if dtype == "float32" else 8
     return 27 * 8 + 3 * nb * es
 
 
-def measured_traffic(kernel):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/<PROFILE_TAG>_traffic.json; FETCH_SIZE and WRITE_SIZE need separate passes, so this cannot be
-    collected live).  None when the profile does not cover this kernel / batch."""
+def src_hash():
+    """identifies the kernel sources a committed counter profile belongs to"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "spart-python_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:12]
+
+
+def counters(dtype):
+    """The committed rocprofv3 PMC passes of this build (FETCH_SIZE, WRITE_SIZE and SQ counters need separate passes
+    under the profiler, so they cannot be collected inside this run): per-kernel averages per launch at B = 1M.
+    -> (dict or None, source string, whether the kernel sources are the ones that were profiled)"""
+    name = f"{PROFILE_TAG}_counters_{dtype}.json"
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", PROFILE_TAG + "_traffic.json")))
-        for k, v in d.items():
-            if k.replace(" ", "") == "spart::" + kernel.replace(" ", ""):
-                return v["hbm_bytes_per_launch"]
+        d = json.load(open(os.path.join(ROOT, "profiles", name)))
     except Exception:
-        pass
-    return None
+        return None, None, False
+    return d, "profiles/" + name, d.get("src_hash") == src_hash()
 
 
 def _cpu_worker(job):
@@ -60,19 +77,6 @@ def _cpu_worker(job):
     for i in range(0, len(P), 256):
         O.spart_run(P[i:i + 256], sensor, T, **kw)
     return time.perf_counter() - t0
-
-
-def measured_valu(kern_s):
-    """VALU issue figures of the band kernel from the committed SQ counter pass (profiles/<PROFILE_TAG>_valu.json):
-    wave-instructions per launch, and the fraction of the chip's VALU issue slots they fill at the 2-cycle wave64
-    fp32 cadence (1024 SIMDs, 2.4 GHz peak clock) over the launch duration measured in THIS run."""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", PROFILE_TAG + "_valu.json")))
-        n, t = d["SQ_INSTS_VALU"], d.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
-        return {"wave_insts_per_launch": n, "transcendental_wave_insts": t,
-                "issue_frac": n * 2.0 / (1024 * 2.4e9 * kern_s)}
-    except Exception:
-        return {}
 
 
 def cpu_baseline(sensor, rows_per_core, seed):
@@ -101,15 +105,132 @@ def cpu_baseline(sensor, rows_per_core, seed):
                                           f"integrals (e1='quad', pso='quad'), {qdt:.1f} s wall"}}
 
 
+def roofline(dtype, B, nb, stage_ms, step_ms, band_kernel):
+    """The dominant kernel is the fused band kernel; it is VALU-issue bound, so `achieved` is the
+    reference's arithmetic per spectrum (flop-equivalents) per second of that kernel against the vector peak.  The HBM
+    side the metric asks for is the `hbm` sub-object: algorithmic bytes over the whole step, and the step-level counter
+    traffic of all of the step's kernels."""
+    kern_s = stage_ms["bands"] / 1e3
+    peak = VALU_PEAK_TFLOPS[dtype]
+    achieved = FLOP_EQ_PER_SPECTRUM * B / kern_s / 1e12
+    ab = algorithmic_bytes(nb, dtype)
+    hbm = {"algorithmic_bytes_per_spectrum": ab, "survey_8d_bytes_per_spectrum": 27 * 4 + 3 * nb * (4 if dtype == "float32" else 8),
+           "achieved_GBps": ab * B / (step_ms / 1e3) / 1e9, "peak_GBps": HBM_PEAK_GBS,
+           "frac": ab * B / (step_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
+           "note": "algorithmic bytes over the whole step's time; the fused path moves a few hundred bytes per 8.7e5 "
+                   "flop-eq, so this is << 1 by construction"}
+    r = {"bound": "valu", "kernel": band_kernel, "kernel_ms": kern_s * 1e3, "achieved": achieved, "peak": peak,
+         "unit": "TFLOP/s", "frac": achieved / peak, "flop_eq_per_spectrum": FLOP_EQ_PER_SPECTRUM,
+         "stage_ms": stage_ms, "traffic": None, "hbm": hbm}
+    c, source, fresh = counters(dtype)
+    if c is not None and B == c.get("batch") and nb == c.get("nb"):
+        k = c["kernels"]
+        bk = next((v for n, v in k.items() if n.replace(" ", "") == band_kernel.replace(" ", "")), None)
+        if bk and "SQ_INSTS_VALU" in bk:
+            r["issue"] = {"valu_wave_insts_per_launch": bk["SQ_INSTS_VALU"],
+                          "transcendental_wave_insts": bk.get("SQ_INSTS_VALU_TRANS_F32"),
+                          "issue_frac": bk["SQ_INSTS_VALU"] * ISSUE_CYCLES[dtype] / (1024 * 2.4e9 * kern_s),
+                          "note": f"VALU wave-instructions x {ISSUE_CYCLES[dtype]:g} cycles / (1024 SIMDs x 2.4 GHz x kernel_ms of THIS run)",
+                          "source": source, "profiled_sources_match": fresh}
+        step_bytes = sum(v.get("hbm_bytes", 0.0) for v in k.values() if v.get("in_step"))
+        if step_bytes:
+            r["traffic"] = step_bytes
+            hbm.update({"counter_bytes_per_step": step_bytes, "ratio_to_algorithmic": step_bytes / (ab * B),
+                        "counter_bytes_per_kernel": {n: v["hbm_bytes"] for n, v in k.items() if v.get("in_step")},
+                        "correction": c.get("correction"), "source": source, "profiled_sources_match": fresh})
+    return r
+
+
+def timed(torch, fn, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def run_config(torch, eng, P, dtype, steps, warmup, graph=False, **kw):
+    """spectra/s of eng.run over the resident batch P + the per-stage HIP-event split (a separate pass when the timed
+    steps are HIP-graph replays: events cannot be recorded inside a graph)."""
+    B = P.shape[1]
+    td = torch.float32 if dtype == "float32" else torch.float64
+    out = {k: torch.empty((B, eng.nb), dtype=td, device=P.device) for k in ("R_TOC", "R_TOA", "L_TOA")}
+    step = lambda: eng.run(P, dtype, out=dict(out), **kw)          # noqa: E731
+    if graph:
+        step = eng.capture(P, dtype, out=out, **kw)
+    sec = timed(torch, step, steps, warmup)
+    eng.profile(steps)
+    for _ in range(steps):
+        eng.run(P, dtype, out=dict(out), **kw)
+    st, n = eng.profile_read_stages()
+    eng.profile(0)
+    ok = all(bool(torch.isfinite(v).all().item()) for v in out.values())
+    return {"value": B / sec, "unit": "spectra/s", "ms_per_step": sec * 1e3, "batch": B, "steps": steps,
+            "stage_ms": {k: v / max(n, 1) for k, v in st.items()}, "finite": ok, "hip_graph": bool(graph)}
+
+
+def extras(torch, args, dev):
+    """Driver-timed sub-records at N = 1: the float64 mode of the headline workload and BASELINE configs 2, 3, 5."""
+    from spart_amd import get_engine, workloads
+    steps = max(3, min(args.steps, 10))
+    eng = get_engine(args.sensor, dev.index)
+    P = torch.as_tensor(workloads.lhs_params(args.batch, "full").T.copy(), device=dev)
+    r = run_config(torch, eng, P, "float64", steps, 1)
+    r["roofline"] = roofline("float64", args.batch, eng.nb, r["stage_ms"], r["ms_per_step"], "k_bands<double, 0, 1, true>")
+    r["dtype"] = "f64"
+    fp64 = r
+    cfg = {}
+    # config 2: PROSPECT-5D leaf only, 10k x 2001, fp64: outputs refl, tran, kChlrel (48 096 B per leaf spectrum)
+    eng0 = get_engine(None, dev.index)
+    Pl = workloads.lhs_params(10_000, "leaf")
+    cols = [torch.as_tensor(Pl[:, i].copy(), device=dev) for i in range(9)]
+    sec = timed(torch, lambda: eng0.prospect(cols, "float64"), 50, 5)
+    by = 9 * 8 + 3 * 2001 * 8
+    cfg["2"] = {"workload": "PROSPECT-5D leaf only, 10k LeafBiology samples x 2001 bands, fp64, refl + tran + kChlrel out",
+                "value": 10_000 / sec, "unit": "leaf spectra/s", "ms_per_step": sec * 1e3, "steps": 50,
+                "roofline": {"bound": "hbm", "achieved": by * 10_000 / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": by * 10_000 / sec / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_leaf": by,
+                             "valu_tflop_eq": FLOP_EQ_PER_LEAF * 10_000 / sec / 1e12, "valu_peak_fp64": VALU_PEAK_TFLOPS["float64"],
+                             "note": "whole call (prelude + k_prospect<double>) timed on the host, synchronised"}}
+    del cols
+    # config 3: full SPART, 100k, Sentinel-2A, fp32 (and 125k = the per-GPU shard of config 4 cut in 8)
+    for name, b in (("3", 100_000), ("4_shard_125k", 125_000)):
+        Pb = P[:, :b].contiguous()
+        cfg[name] = run_config(torch, eng, Pb, "float32", 50, 5, graph=True)
+        cfg[name]["workload"] = f"full SPART, {b} spectra of the config-4 LHS, {args.sensor}, fp32, all 2162 bands"
+    # config 5: PROSPECT-PRO + SAILH, 1M, Sentinel-2B, fp32 and fp64 (the tolerance sweep itself is tests/test_gpu_parity.py::
+    # test_float32_tolerance_at_size; here the max deviation of this run is reported next to the rate)
+    del P
+    engb = get_engine("Sentinel2B-MSI", dev.index)
+    Pp = torch.as_tensor(workloads.lhs_params(args.batch, "pro").T.copy(), device=dev)
+    c5 = run_config(torch, engb, Pp, "float32", steps, 1)
+    c5["workload"] = f"PROSPECT-PRO (Cdm = 0, PROT / CBC vary) + SAILH, {args.batch} spectra, Sentinel2B-MSI, fp32"
+    c5f = run_config(torch, engb, Pp, "float64", 3, 1)
+    a, b = engb.run(Pp, "float32"), None
+    a = {k: v.clone() for k, v in a.items()}
+    b = engb.run(Pp, "float64")
+    c5["fp64_value"] = c5f["value"]
+    c5["fp32_vs_fp64_max_rel_floor1e-6"] = {k: float(((a[k].double() - b[k]).abs() / b[k].abs().clamp_min(1e-6)).max().item())
+                                            for k in ("R_TOC", "R_TOA", "L_TOA")}
+    cfg["5"] = c5
+    return fp64, cfg
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=1_000_000, help="spectra per GPU per step")
+    ap.add_argument("--batch", type=int, default=1_000_000, help="GLOBAL batch (strong scaling) / batch per GPU (weak)")
+    ap.add_argument("--scaling", default="auto", choices=["auto", "strong", "weak"],
+                    help="auto = strong for N > 1 (BASELINE config 4: 1M spectra cut into N shards + gather)")
     ap.add_argument("--dtype", default="float32", choices=["float32", "float64"])
     ap.add_argument("--sensor", default="Sentinel2A-MSI")
     ap.add_argument("--cpu-rows", type=int, default=8192, help="rows PER HOST CORE for the CPU baseline (0 = skip)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the fp64 / configs sub-records (profiling runs)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -119,10 +240,9 @@ def main():
         from spart_amd import workloads as _w            # (no torch / HIP import yet: the workers are forked)
         cpu = cpu_baseline(args.sensor, args.cpu_rows, _w.LHS_SEED)
 
-    import numpy as np
     import torch
     import torch.distributed as dist
-    from spart_amd import get_engine, workloads
+    from spart_amd import get_engine, sharding, workloads
 
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
@@ -140,18 +260,28 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    B = args.batch
+    scaling = args.scaling if args.scaling != "auto" else ("strong" if world > 1 else "weak")
     eng = get_engine(args.sensor, dev_index)
     nb = eng.nb
-    # synthetic inputs: this rank's shard of the LHS workload, resident in HBM before timing starts
-    P = torch.as_tensor(workloads.lhs_params(B, "full", seed=workloads.LHS_SEED + rank).T.copy(), device=dev)
+    # synthetic inputs, resident in HBM before timing starts.  strong: this rank's contiguous shard of ONE global LHS
+    # table (spart_amd.sharding.shard_bounds); weak: every rank its own table (seed + rank)
+    if scaling == "strong":
+        Bg = args.batch
+        lo, hi = sharding.shard_bounds(Bg, world, rank)
+        per = -(-Bg // world)                            # gather block: the last shards may be short (padded with zeros)
+        P = torch.as_tensor(workloads.lhs_params(Bg, "full", seed=workloads.LHS_SEED)[lo:hi].T.copy(), device=dev)
+    else:
+        Bg = args.batch * world
+        lo, hi, per = 0, args.batch, args.batch
+        P = torch.as_tensor(workloads.lhs_params(args.batch, "full", seed=workloads.LHS_SEED + rank).T.copy(), device=dev)
+    B = hi - lo
     td = torch.float32 if args.dtype == "float32" else torch.float64
-    # (3, B, nb) so that the three result columns travel in ONE gather.  Two result buffers: the gather of
+    # (3, per, nb) so that the three result columns travel in ONE gather.  Two result buffers: the gather of
     # step i (RCCL's own stream) overlaps the kernels of step i + 1 (compute stream); a buffer is reused
     # only after its gather has completed.  Every gather is inside the timed region (fence() waits for all).
     nbuf = 2 if world > 1 else 1
-    res = [torch.empty((3, B, nb), dtype=td, device=dev) for _ in range(nbuf)]
-    outs = [{"R_TOC": r[0], "R_TOA": r[1], "L_TOA": r[2]} for r in res]
+    res = [torch.zeros((3, per, nb), dtype=td, device=dev) for _ in range(nbuf)]
+    outs = [{"R_TOC": r[0, :B], "R_TOA": r[1, :B], "L_TOA": r[2, :B]} for r in res]
     gather_lists = [[torch.empty_like(res[0]) for _ in range(world)] if rank == 0 else None
                     for _ in range(nbuf)] if world > 1 else None
     works = [None] * nbuf
@@ -163,7 +293,8 @@ def main():
         if works[j] is not None:
             works[j].wait()                     # compute stream waits until buffer j's previous gather is done
             works[j] = None
-        eng.run(P, args.dtype, out=outs[j])     # opt = NULL: all 2162 bands of every spectrum are evaluated
+        if B:
+            eng.run(P, args.dtype, out=dict(outs[j]))   # opt = NULL: all 2162 bands of every spectrum are evaluated
         if world > 1:
             works[j] = dist.gather(res[j], gather_lists[j], dst=0, async_op=True)
 
@@ -186,7 +317,7 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    band_ms, ncalls = eng.profile_read()
+    stage, ncalls = eng.profile_read_stages()
     eng.profile(0)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -195,35 +326,34 @@ def main():
 
     if rank == 0:
         ok = all(bool(torch.isfinite(r).all().item()) for r in res)
-        total = B * world * args.steps
-        value = total / dt
-        kern_s = band_ms / max(ncalls, 1) / 1e3
-        abytes = algorithmic_bytes(nb, args.dtype) * B          # per launch of the band kernel's step
-        std = args.dtype == "float32" and B == 1_000_000 and args.sensor == "Sentinel2A-MSI"   # the profiled configuration
-        achieved = abytes / kern_s / 1e9
+        if world > 1:
+            ok = ok and all(bool(torch.isfinite(g).all().item()) for gl in gather_lists for g in gl)
+        value = Bg * args.steps / dt
+        stage_ms = {k: v / max(ncalls, 1) for k, v in stage.items()}
+        band_kernel = "k_bands<float, 0, 1, false>" if args.dtype == "float32" else "k_bands<double, 0, 1, true>"
         line = {
-            "metric": "SPART spectra/sec (R_TOC+R_TOA+L_TOA) at batch 1M; achieved HBM GB/s vs peak",
+            "metric": METRIC,
             "value": value, "unit": "spectra/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f32" if args.dtype == "float32" else "f64", "data": "synthetic",
-            "config": {"workload": "full SPART (BSM+PROSPECT-5D+SAILH+SMAC), 22-D Latin hypercube (seed 20240613+rank), "
-                                   f"{args.sensor}, all 2162 bands evaluated per spectrum, columns-only output",
-                       "batch_per_gpu": B, "global_batch": B * world, "bands_evaluated": 2162, "sensor_bands": nb,
-                       "parallelism": f"dp{world} (independent shards + one RCCL gather to rank 0 per step, overlapped with "
-                                      "the next step's kernels)" if world > 1 else "single GPU",
-                       "input_dtype": "f64", "finite": ok},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic("k_bands<float,0,1>") if std else None,
-                         "kernel": "k_bands<float,0,1>" if args.dtype == "float32" else "k_bands<double,0,1>",
-                         "kernel_ms": kern_s * 1e3, "algorithmic_bytes_per_spectrum": algorithmic_bytes(nb, args.dtype),
-                         "note": "fused path is VALU/transcendental bound by design (SURVEY.md §8d); HBM fraction is "
-                                 "reported because the metric asks for it",
-                         "valu": dict({"flop_eq_per_spectrum": 8.7e5,
-                                       "achieved_tflop_eq": 8.7e5 * B / kern_s / 1e12, "peak_fp32_tflops": FP32_VALU_TFLOPS},
-                                      **(measured_valu(kern_s) if std else {}))},
+            "config": {"workload": "BASELINE config 4: full SPART (BSM+PROSPECT-5D+SAILH+SMAC), 22-D Latin hypercube "
+                                   f"(seed 20240613), {args.sensor}, all 2162 bands evaluated per spectrum, columns-only output",
+                       "global_batch": Bg, "batch_per_gpu": B if scaling == "strong" else args.batch,
+                       "bands_evaluated": 2162, "sensor_bands": nb,
+                       "parallelism": (f"dp{world}: {'one 1M LHS table cut into contiguous shards' if scaling == 'strong' else 'one table per rank'}"
+                                       " + one RCCL gather of the (3, B/N, nb) block to rank 0 per step, overlapped with the next "
+                                       "step's kernels") if world > 1 else "single GPU",
+                       "input_dtype": "f64",
+                       "columns": ("float32 full-band pass + float64 re-evaluation of the sensor-slot bands: columns = the float64 "
+                                   "mode's, rounded once") if args.dtype == "float32" else "float64 throughout",
+                       "tables": "17 table values per band held in VGPRs (lane = band); the per-sample constants, not the tables, "
+                                 "are staged through LDS (north_star says tables in LDS; measured slower, DESIGN.md section 4)",
+                       "finite": ok},
+            "roofline": roofline(args.dtype, B, nb, stage_ms, dt / args.steps * 1e3, band_kernel),
         }
         line["cpu_baseline"] = cpu
+        if world == 1 and not args.no_extras and args.dtype == "float32":
+            line["fp64"], line["configs"] = extras(torch, args, dev)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

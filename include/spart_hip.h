@@ -159,12 +159,16 @@ int spart_lut_nearest(spart_ctx *ctx, int dtype, int64_t B, int nb, const void *
                       const void *weights, int64_t *best_idx, void *best_cost, void *workspace, size_t workspace_bytes,
                       void *stream);
 
-/* Measurement aid (bench.py): when enabled, spart_run_batch brackets its dominant kernel (the
- * fused band kernel) with HIP events recorded on the caller's stream, for up to max_calls calls;
- * spart_profile_read waits for them and returns the summed kernel time and the number of calls.
- * max_calls = 0 disables. */
+/* Measurement aid (bench.py): when enabled, spart_run_batch brackets each of its kernels with HIP events recorded on
+ * the caller's stream, for up to max_calls calls (max_calls = 0 disables).  spart_profile_read_stages waits for them
+ * and returns the summed milliseconds per stage -- [0] prelude (per-sample constants), [1] the fused full-band kernel
+ * (PROSPECT + BSM + SAILH, the dominant one), [2] the float64 sensor-slot pass, [3] the sensor kernel (interpolation,
+ * SMAC, TOC->TOA; includes the band-mean reduction when requested) -- and the number of timed calls;
+ * spart_profile_read returns stage [1] only. */
+#define SPART_NSTAGE 4
 int spart_profile_enable(spart_ctx *ctx, int max_calls);
 int spart_profile_read(spart_ctx *ctx, double *total_ms, int *ncalls);
+int spart_profile_read_stages(spart_ctx *ctx, double stage_ms[SPART_NSTAGE], int *ncalls);
 
 #ifdef __cplusplus
 }

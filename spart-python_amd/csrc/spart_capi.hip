@@ -34,10 +34,12 @@ struct spart_ctx {
   std::vector<double> econv_host;
   // optional timing of the dominant kernel (k_bands): event pairs recorded on the caller's stream
   bool profile = false;
-  std::vector<hipEvent_t> ev;   // start0, stop0, start1, stop1, ...
+  std::vector<hipEvent_t> ev;   // NEV events per timed call (run_impl)
   size_t ev_used = 0;
   mutable char err[512] = {0};
 };
+
+constexpr size_t NEV = 5;        // events per timed spart_run_batch call: 4 stage intervals
 
 static thread_local char g_err[512] = {0};
 
@@ -269,6 +271,11 @@ static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_
   TG* G = (TG*)(wsp + ws.g_off);
   TG* gs = (TG*)(wsp + ws.gs_off);
   int rc;
+  // optional per-stage timing: five events per call (before the prelude, after the prelude, the full-band kernel, the
+  // slot pass, the sensor kernel), recorded on the caller's stream
+  const bool prof = ctx->profile && ctx->ev_used + NEV <= ctx->ev.size();
+  hipEvent_t* ev = prof ? &ctx->ev[ctx->ev_used] : nullptr;
+  if (prof) HIP_TRY(ctx, hipEventRecord(ev[0], st));
   {
     Range r("SPART prelude (geometry, LIDF, hot spot, soil factors)");
     // legacy float32 columns: the fast prelude; otherwise the literal one, so that the default float32 mode's
@@ -303,8 +310,7 @@ static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_
   const bool full = !(opt && opt->prune_unused_bands);
   if (opt && opt->band_mean && !full)
     return fail(ctx, SPART_ERR_INVALID, "spart_run_batch: band_mean needs prune_unused_bands = 0");
-  const bool prof = ctx->profile && ctx->ev_used + 2 <= ctx->ev.size();
-  if (prof) HIP_TRY(ctx, hipEventRecord(ctx->ev[ctx->ev_used], st));
+  if (prof) HIP_TRY(ctx, hipEventRecord(ev[1], st));
   // hybrid: the full-band kernel stores no G rows; they come from the float64 slot pass below
 #define SPART_LAUNCH_BANDS(M, F)                                                                                 \
   hipLaunchKernelGGL((k_bands<T, M, F, !HYBRID>), grid, dim3(TILE), 0, st, tab, cst, Bp, (const int*)ctx->need_slot, \
@@ -322,10 +328,7 @@ static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_
   else slots_done = false;                     // columns only, pruning allowed: evaluate just the sensor's bands
 #undef SPART_LAUNCH_BANDS
   HIP_TRY(ctx, hipGetLastError());
-  if (prof) {
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[ctx->ev_used + 1], st));
-    ctx->ev_used += 2;
-  }
+  if (prof) HIP_TRY(ctx, hipEventRecord(ev[2], st));
   if (!slots_done) {
     const int64_t nblk = (B + 255) / 256;                              // 256-sample blocks, dealt to the XCDs in groups of 8
     hipLaunchKernelGGL((k_slots<TG, T>), dim3((unsigned)(((nblk + 7) / 8) * 8 * ctx->nslot)), dim3(256), 0, st, tabG,
@@ -333,6 +336,7 @@ static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_
                        (const T*)(opt ? opt->rdry_in : nullptr), ctx->po, B, ctx->nslot);
     HIP_TRY(ctx, hipGetLastError());
   }
+  if (prof) HIP_TRY(ctx, hipEventRecord(ev[3], st));
   if (opt && opt->band_mean) {
     hipLaunchKernelGGL((k_bandmean<T>), dim3((4 * NWLS + 255) / 256), dim3(256), 0, st, (const T*)bsum, nchunk, B,
                        (T*)opt->band_mean);
@@ -353,6 +357,10 @@ static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_
                        (T*)(opt ? opt->rsoil : nullptr), (T*)(opt ? opt->La : nullptr));
   }
   HIP_TRY(ctx, hipGetLastError());
+  if (prof) {
+    HIP_TRY(ctx, hipEventRecord(ev[4], st));
+    ctx->ev_used += NEV;
+  }
   return SPART_OK;
 }
 
@@ -554,7 +562,7 @@ int spart_profile_enable(spart_ctx* ctx, int max_calls) {
   DeviceGuard guard(ctx->device);
   ctx->profile = max_calls > 0;
   ctx->ev_used = 0;
-  while (ctx->ev.size() < (size_t)(max_calls > 0 ? 2 * max_calls : 0)) {
+  while (ctx->ev.size() < (size_t)(max_calls > 0 ? NEV * max_calls : 0)) {
     hipEvent_t e;
     HIP_TRY(ctx, hipEventCreate(&e));
     ctx->ev.push_back(e);
@@ -562,22 +570,32 @@ int spart_profile_enable(spart_ctx* ctx, int max_calls) {
   return SPART_OK;
 }
 
-int spart_profile_read(spart_ctx* ctx, double* total_ms, int* ncalls) {
-  if (!ctx || !total_ms || !ncalls) return fail(ctx, SPART_ERR_INVALID, "spart_profile_read: null argument");
+int spart_profile_read_stages(spart_ctx* ctx, double stage_ms[SPART_NSTAGE], int* ncalls) {
+  if (!ctx || !stage_ms || !ncalls) return fail(ctx, SPART_ERR_INVALID, "spart_profile_read_stages: null argument");
   DeviceGuard guard(ctx->device);
-  double tot = 0.0;
+  static_assert(SPART_NSTAGE + 1 == NEV, "one event more than stages");
+  for (int k = 0; k < SPART_NSTAGE; ++k) stage_ms[k] = 0.0;
   int n = 0;
-  for (size_t i = 0; i + 1 < ctx->ev_used; i += 2) {
-    HIP_TRY(ctx, hipEventSynchronize(ctx->ev[i + 1]));
-    float ms = 0.f;
-    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]));
-    tot += ms;
+  for (size_t i = 0; i + NEV <= ctx->ev_used; i += NEV) {
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev[i + NEV - 1]));
+    for (int k = 0; k < SPART_NSTAGE; ++k) {
+      float ms = 0.f;
+      HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[i + k], ctx->ev[i + k + 1]));
+      stage_ms[k] += ms;
+    }
     ++n;
   }
   ctx->ev_used = 0;
-  *total_ms = tot;
   *ncalls = n;
   return SPART_OK;
+}
+
+int spart_profile_read(spart_ctx* ctx, double* total_ms, int* ncalls) {
+  if (!ctx || !total_ms || !ncalls) return fail(ctx, SPART_ERR_INVALID, "spart_profile_read: null argument");
+  double st[SPART_NSTAGE];
+  int rc = spart_profile_read_stages(ctx, st, ncalls);
+  *total_ms = st[1];
+  return rc;
 }
 
 size_t spart_workspace_bytes(const spart_ctx* ctx, int dtype, int64_t B) {

@@ -50,7 +50,9 @@ SIGNATURES = {
                                          vp, ctypes.c_size_t, vp]),
     "spart_profile_enable": (ctypes.c_int, [vp, ctypes.c_int]),
     "spart_profile_read": (ctypes.c_int, [vp, c_dp, ctypes.POINTER(ctypes.c_int)]),
+    "spart_profile_read_stages": (ctypes.c_int, [vp, c_dp, ctypes.POINTER(ctypes.c_int)]),
 }
+STAGES = ("prelude", "bands", "slots", "sensor")        # spart_profile_read_stages
 
 _libs = {}
 

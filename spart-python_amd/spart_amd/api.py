@@ -271,14 +271,23 @@ def SMAC(angles, atm, coefs, device=None):
 
 
 def _engine_for_coefs(coefs, device):
-    key = id(coefs)
+    """One engine per (coefficient CONTENT, device): the reference's calling convention is
+    SMAC(angles, atm, sensorinfo['SMAC_coef']) with a freshly loaded dict each time, so the dict's identity says
+    nothing (CPython reuses the address of the previous, freed dict); the key is a digest of the stacked 48 x nb
+    float64 coefficient block."""
+    import hashlib
+    import torch
+    dev = int(torch.cuda.current_device() if device is None else device)
+    block = np.ascontiguousarray(np.stack([np.asarray(coefs[n], dtype=np.float64).reshape(-1) for n in _tables.COEF_NAMES]))
+    key = (hashlib.sha1(block.tobytes()).hexdigest(), block.shape[1], dev)
     cache = _engine_for_coefs.__dict__.setdefault("cache", {})
     if key not in cache:
-        nb = np.asarray(coefs["taur"]).size
+        if len(cache) >= 16:                      # a handful of sensors at most: do not hold device tables forever
+            cache.pop(next(iter(cache)))
+        nb = block.shape[1]
         si = {"wl_smac": np.full((nb, 1), 500.0), "band_id_smac": [""] * nb, "SMAC_coef": coefs,
               "wl_srf_smac": np.full((1, nb), 500.0), "p_srf_smac": np.ones((1, nb))}
-        import torch
-        cache[key] = _engine.Engine(None, torch.cuda.current_device() if device is None else device, sensor_info=si)
+        cache[key] = _engine.Engine(None, dev, sensor_info=si)
     return cache[key]
 
 
@@ -408,6 +417,9 @@ class SPART:
         bands = self.sensorinfo["band_id_smac"]
         # attributes documented at SPART.py:66-81
         self.R_TOC, self.R_TOA, self.L_TOA, self._La = out["R_TOC"], out["R_TOA"], out["L_TOA"], out["La"]
+        # atmopt (SPART.py:226-232): the nine SMAC fields, (1, nb) each for scalar inputs (smac.py:209-211), (B, nb) otherwise
+        sm = eng.smac(self.angles.columns(), self.atm.columns())
+        self.atmopt = AtmosphericOptics(*[_np(sm[f]) for f in _engine.SMAC_FIELDS])
         if materialize:
             sc = scalar
             col = (lambda a: a[0][:, None].copy()) if sc else (lambda a: a)

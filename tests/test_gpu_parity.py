@@ -2,6 +2,8 @@
 reference's golden vectors.  Tolerances: north_star's 1e-6 rel (fp64) / 1e-4 rel (fp32) on the
 sensor columns; spectra use the same relative bound with an absolute floor matching the
 reference's own unit-test precision (assert_almost_equal: 1.5e-7 leaf, 1.5e-6 canopy)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -251,6 +253,24 @@ def test_reference_style_api(golden, torch_mod, capsys):
     df2 = SPART.SPART(SPART.SoilParameters(0.5, 0, 100, 20, 25, 0.015), pro, canopy,
                       SPART.AtmosphericProperties(0.325, 0.35, 1.41), angles, "Sentinel2B-MSI", 100).run()
     assert "PROSPECT-PRO was called" in capsys.readouterr().out
+    # atmopt (SPART.py:66-81, 226-232; smac.py:209-211) is set by every run(): golden SMAC row 0 = these defaults
+    gs = golden["smac"]
+    sp = SPART.SPART(SPART.SoilParameters(0.5, 0, 100, 20, 25, 0.015), SPART.LeafBiology(40, 0.01, 0.02, 0, 10, 10, 1.5), canopy,
+                     SPART.AtmosphericProperties(0.325, 0.35, 1.41), angles, "Sentinel2A-MSI", 100)
+    sp.run()
+    assert np.array_equal(gs["Sentinel2A-MSI/angles"][0], [40, 0, 0]) and np.allclose(gs["Sentinel2A-MSI/atm"][0], [0.325, 0.35, 1.41, 1013.25])
+    for f in ("Ta_s", "Ta_o", "Tg", "Ra_dd", "Ra_so", "Ta_ss", "Ta_sd", "Ta_oo", "Ta_do"):
+        a = getattr(sp.atmopt, f)
+        assert a.shape == (1, 13)
+        assert rel_err(a[0], gs[f"Sentinel2A-MSI/{f}"][0], 1e-3) < 2e-6, f
+    # the reference's calling convention SMAC(angles, atm, sensorinfo["SMAC_coef"]) with a fresh dict per call: two
+    # sensors back to back must not share an engine (the dicts may share an id())
+    for sensor in ("Sentinel2A-MSI", "TerraAqua-MODIS", "LANDSAT8-OLI"):
+        ao = SPART.SMAC(SPART.Angles(*gs[f"{sensor}/angles"][2]), SPART.AtmosphericProperties(*gs[f"{sensor}/atm"][2]),
+                        SPART.load_sensor_info(sensor)["SMAC_coef"])
+        tol = 2e-6 if sensor.startswith("Sentinel2") else 1e-9
+        for f in ("Tg", "Ra_so", "Ta_ss", "Ta_do"):
+            assert rel_err(getattr(ao, f)[0], gs[f"{sensor}/{f}"][2], 1e-3) < tol, (sensor, f)
     assert abs(df2["R_TOC"].iloc[0] / 0.016457380856374198 - 1) < 1e-6
     assert abs(df2["R_TOA"].iloc[5] / 0.3058118531440649 - 1) < 1e-6
     # stage functions with reference shapes
@@ -390,14 +410,45 @@ def test_lut_generation_streams_chunks(tmp_path, torch_mod):
     mem = spart_amd.generate_lut(P[:100], "Sentinel2A-MSI", dtype="float64", chunk=64)
     ref64 = eng.run(torch_mod.as_tensor(P[:100].T.copy(), device="cuda:0"), "float64")
     assert np.array_equal(mem["R_TOC"], ref64["R_TOC"].cpu().numpy())
-    try:                                   # parquet export needs a working pyarrow / fastparquet engine
-        pq = spart_amd.lut_to_parquet(d, str(tmp_path / "lut.gzip"))
-    except ImportError as e:
-        print("parquet engine unavailable on this box:", e)
-        return
+    # (the parquet export of such a directory is covered without a GPU: tests/test_host_logic.py::test_lut_parquet_export,
+    #  and -- where the box has a parquet engine -- end to end in test_lut_on_disk_parquet_leg below)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_lut_on_disk_matches_the_reference_rows(golden, dtype, tmp_path, torch_mod):
+    """What generate_lut lands ON DISK against the real reference: the 256 golden rows of the config-4 LHS
+    (tests/golden/e2e.npz, lhs_full/Sentinel2A-MSI), streamed in ragged chunks of 100 (3 chunks, the last of 56)
+    through the upload / launch / download pipeline and read back from the .npy files."""
+    import spart_amd
+    g = golden["e2e"]
+    P = g["lhs_full/Sentinel2A-MSI/P"]
+    d = str(tmp_path / "lut")
+    spart_amd.generate_lut(P, "Sentinel2A-MSI", path=d, dtype=dtype, chunk=100)
+    meta, params, cols = spart_amd.load_lut(d, mmap=False)
+    assert meta["rows"] == 256 and meta["dtype"] == dtype and np.array_equal(params, P)
+    for k in ("R_TOC", "R_TOA", "L_TOA"):
+        arr = np.load(os.path.join(d, k + ".npy"))                        # the file itself, not the returned memmap
+        assert arr.shape == (256, 13) and arr.dtype == (np.float64 if dtype == "float64" else np.float32)
+        assert rel_err(arr, g[f"lhs_full/Sentinel2A-MSI/{k}"], COLFLOOR) < TOL[dtype], k
+        assert np.array_equal(arr, np.asarray(cols[k]))
+
+
+def test_lut_on_disk_parquet_leg(golden, tmp_path, torch_mod):
+    """generate_lut -> lut_to_parquet -> pandas.read_parquet against the reference's golden rows.  The GPU boxes of this
+    pool ship pandas without a parquet engine: that is reported as a SKIP here (never a silent pass); the export itself
+    is asserted on the CPU suite (tests/test_host_logic.py::test_lut_parquet_export), where an engine is present."""
+    pytest.importorskip("pyarrow", reason="no parquet engine on this box (export covered by tests/test_host_logic.py)")
     import pandas as pd
-    df = pd.read_parquet(pq)
-    assert df.shape == (B, 27 + 3 * 13) and abs(df["R_TOC_445"].iloc[5] - ref["R_TOC"][5, 0]) == 0
+    import spart_amd
+    g = golden["e2e"]
+    d = str(tmp_path / "lut")
+    spart_amd.generate_lut(g["lhs_full/Sentinel2A-MSI/P"], "Sentinel2A-MSI", path=d, dtype="float64", chunk=100)
+    meta, _, _ = spart_amd.load_lut(d)
+    df = pd.read_parquet(spart_amd.lut_to_parquet(d, str(tmp_path / "lut.parquet")))
+    assert list(df.columns[:27]) == meta["param_names"] and df.shape == (256, 27 + 39)
+    for k in ("R_TOC", "R_TOA", "L_TOA"):
+        tab = df[[f"{k}_{w:g}" for w in meta["wavelengths"]]].to_numpy()
+        assert rel_err(tab, g[f"lhs_full/Sentinel2A-MSI/{k}"], COLFLOOR) < 1e-6, k
 
 
 @pytest.mark.parametrize("dtype,nb", [("float32", 13), ("float64", 13), ("float32", 6), ("float32", 21)])

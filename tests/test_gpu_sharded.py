@@ -1,0 +1,107 @@
+"""The HIP + collective leg of the sharded path (spart_amd.sharding) on the one GPU of the test box:
+
+* a world-size-1 `nccl` (= RCCL) process group: run_sharded(P, default_evaluate(...)) -- the real evaluator and a
+  real RCCL gather of device tensors -- against the reference's golden rows of the config-4 LHS;
+* two ranks under `gloo`, BOTH on device 0, each running the HIP evaluator on its shard (ragged: 257 rows), the
+  gathered result compared bit for bit with a single-rank evaluation of the whole batch.
+
+8-GPU RCCL runs are the driver's (bench.py --gpus 8); nothing here claims them."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.normpath(os.path.join(HERE, ".."))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _nccl_world1(port, q):
+    """own process: a process group cannot be re-initialised inside the pytest process once destroyed elsewhere"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, os.path.join(ROOT, "spart-python_amd"))
+    import torch
+    import torch.distributed as dist
+    from spart_amd import sharding
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    g = np.load(os.path.join(HERE, "golden", "e2e.npz"))
+    P = torch.as_tensor(g["lhs_full/Sentinel2A-MSI/P"].T.copy(), device="cuda:0")
+    out = {}
+    for dtype in ("float64", "float32"):
+        res = sharding.run_sharded(P, sharding.default_evaluate("Sentinel2A-MSI", dtype, 0))
+        torch.cuda.synchronize()
+        out[dtype] = res.double().cpu().numpy()
+    q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_hip_path_under_nccl_world1(golden):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_world1, args=(_free_port(), q))
+    p.start()
+    out = q.get(timeout=300)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    g = golden["e2e"]
+    for dtype, tol in (("float64", 1e-6), ("float32", 1e-4)):
+        assert out[dtype].shape == (3, 256, 13)
+        for i, k in enumerate(("R_TOC", "R_TOA", "L_TOA")):
+            assert rel_err(out[dtype][i], g[f"lhs_full/Sentinel2A-MSI/{k}"], 1e-6) < tol, (dtype, k)
+
+
+def _gloo_hip_rank(rank, world, port, B, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, os.path.join(ROOT, "spart-python_amd"))
+    import torch
+    import torch.distributed as dist
+    from spart_amd import sharding, workloads
+    torch.cuda.set_device(0)                                        # both ranks share the one GPU
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    P = torch.as_tensor(workloads.lhs_params(B, "full", seed=12).T.copy())
+    ev = sharding.default_evaluate("Sentinel2A-MSI", "float32", 0)
+
+    def evaluate(Ps):                                               # HIP evaluator, result handed to gloo on the host
+        return ev(Ps.to("cuda:0")).cpu()
+
+    res = sharding.run_sharded(P, evaluate)
+    if rank == 0:
+        full = evaluate(P)
+        q.put((tuple(res.shape), bool(torch.equal(res, full)), bool(torch.isfinite(res).all())))
+    else:
+        assert res is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_gloo_ranks_with_the_hip_evaluator_match_single_rank():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port, B = _free_port(), 257
+    procs = [ctx.Process(target=_gloo_hip_rank, args=(r, 2, port, B, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    shape, same, finite = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert shape == (3, B, 13) and finite
+    assert same                                                    # shards are independent: bit-identical to one rank

@@ -1,47 +1,132 @@
-"""Copy the summaries of gpurun_out/<tag>/ (tools/collect_profiles.sh) into profiles/<tag>_* and derive <tag>_traffic.json."""
-import collections, csv, glob, json, os, shutil, sys
+"""Copy the summaries of gpurun_out/<tag>/ (tools/collect_profiles.sh) into profiles/<tag>_* and derive the
+per-kernel counter files bench.py reads: profiles/<round>_counters_<dtype>.json.
+
+    python tools/ingest_profiles.py r2_a [r2]     (second argument: the prefix bench.py's PROFILE_TAG names)"""
+import collections
+import csv
+import glob
+import hashlib
+import json
+import os
+import shutil
+import sys
+
 ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 tag = sys.argv[1]
+prefix = sys.argv[2] if len(sys.argv) > 2 else tag.split("_")[0]
 src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
-res = {}
-for d, c in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
-    f = glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv"))[0]
-    acc = collections.defaultdict(list)
+
+
+def src_hash():
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "spart-python_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:12]
+
+
+def one(pattern):
+    g = glob.glob(os.path.join(src, pattern))
+    return g[0] if g else None
+
+
+def per_kernel(f, counters=None):
+    """{kernel: {counter: average per dispatch}} (a counter's rows of one dispatch are summed: XCDs / SEs)"""
+    acc = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(float)))
     for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] == c and "spart" in r["Kernel_Name"]:
-            acc[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
-    for k, v in acc.items():
-        res.setdefault(k, {})[c + "_KB_per_launch"] = sum(v) / len(v)
-    shutil.copy(f, os.path.join(dst, f"{tag}_{d}_counter_collection.csv"))
-for k, v in res.items():
-    v["hbm_bytes_per_launch"] = (v.get("FETCH_SIZE_KB_per_launch", 0) + v.get("WRITE_SIZE_KB_per_launch", 0)) * 1024
-res["_note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --steps 3 --warmup 1 --cpu-rows 0` "
-                "(B = 1M, Sentinel2A, fp32); KB per launch as rocprofv3 reports them, hbm_bytes = (FETCH+WRITE)*1024. Reads are "
-                "4-B-per-lane coalesced loads of the 192 B/sample constants and writes are 16-B / 4-B per-lane stores, for which "
-                "the gfx950 FETCH_SIZE 1/2-factor of wide (16 B/lane) streams is not calibrated (MI355X_MICROARCH.md, HBM); no "
-                "correction applied.")
-json.dump(res, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
-shutil.copy(glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
-shutil.copy(glob.glob(os.path.join(src, "pmc_sq", "*", "*_counter_collection.csv"))[0], os.path.join(dst, f"{tag}_pmc_sq_counter_collection.csv"))
-# per-launch SQ counters of the band kernel -> <tag>_valu.json (read by bench.py for roofline.valu)
-sq = collections.defaultdict(lambda: collections.defaultdict(float))
-for r in csv.DictReader(open(os.path.join(dst, f"{tag}_pmc_sq_counter_collection.csv"))):
-    if "k_bands" in r["Kernel_Name"]:
-        sq[r["Dispatch_Id"]][r["Counter_Name"]] += float(r["Counter_Value"])
-if sq:
-    names = sorted(next(iter(sq.values())))
-    avg = {n: sum(d[n] for d in sq.values()) / len(sq) for n in names}
-    avg["_note"] = ("per launch of the band kernel (B = 1M, fp32), summed over all XCDs / SEs; GRBM_GUI_ACTIVE is the sum over the 8 XCDs "
-                    "(divide by 8 for the kernel's cycles)")
-    json.dump(avg, open(os.path.join(dst, f"{tag}_valu.json"), "w"), indent=1)
-for d in ("mat_stats", "mat_pmc_write"):
-    g = glob.glob(os.path.join(src, d, "*", "*_kernel_stats.csv" if d == "mat_stats" else "*_counter_collection.csv"))
-    if g:
-        shutil.copy(g[0], os.path.join(dst, f"{tag}_{d}.csv"))
-if os.path.exists(os.path.join(src, "mat_bench.txt")):
-    shutil.copy(os.path.join(src, "mat_bench.txt"), os.path.join(dst, f"{tag}_mat_bench.txt"))
-shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, f"{tag}_bench.json"))
-shutil.copy(os.path.join(src, "configs.json"), os.path.join(dst, f"{tag}_configs.json"))
-print(json.dumps({k: v for k, v in res.items() if k != "_note"}, indent=1))
-print(open(os.path.join(src, "bench.json")).read()[:300])
+        if counters and r["Counter_Name"] not in counters:
+            continue
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("spart::", "")
+        acc[k][r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+    return {k: {c: sum(d.values()) / len(d) for c, d in v.items()} for k, v in acc.items()}
+
+
+# ---- calibration of FETCH_SIZE / WRITE_SIZE on 1 GiB moved in this library's access widths
+calib = {}
+for d, c in (("calib_fetch", "FETCH_SIZE"), ("calib_write", "WRITE_SIZE")):
+    f = one(f"{d}/*/*_counter_collection.csv")
+    if f:
+        shutil.copy(f, os.path.join(dst, f"{tag}_{d}.csv"))
+        for k, v in per_kernel(f, {c}).items():
+            if (c == "FETCH_SIZE") == k.startswith("read"):
+                calib[k] = v[c] * 1024 / float(1 << 30)          # counter bytes per byte actually moved
+if calib:
+    json.dump({"_note": "rocprofv3 counter (KB x 1024) / bytes actually moved (1 GiB per kernel, tools/ubench/fetch_calib.hip): "
+                        "FETCH_SIZE for the read_* kernels, WRITE_SIZE for the write_* kernels", **calib},
+              open(os.path.join(dst, f"{tag}_counter_calibration.json"), "w"), indent=1)
+
+
+def corr(kind, width):
+    """divide a counter by this to get bytes: calibration of the nearest access pattern, 1.0 when not calibrated"""
+    name = {("r", 4): "read_coalesced<float>", ("r", 8): "read_coalesced<double>", ("r", 16): "read_coalesced<HIP_vector_type<float, 4u> >",
+            ("r", "seg"): "read_segments", ("w", 4): "write_coalesced<float>", ("w", 8): "write_coalesced<double>",
+            ("w", 16): "write_coalesced<HIP_vector_type<float, 4u> >", ("w", "g"): "write_strided16"}[(kind, width)]
+    return calib.get(name, 1.0)
+
+
+# ---- the step's kernels, per dtype
+for dt in ("float32", "float64"):
+    fs = {c: one(f"pmc_{d}_{dt}/*/*_counter_collection.csv") for d, c in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE"), ("sq", "SQ"))}
+    if not all(fs.values()):
+        continue
+    kern = collections.defaultdict(dict)
+    for c, f in fs.items():
+        shutil.copy(f, os.path.join(dst, f"{tag}_pmc_{c.lower().replace('_size', '')}_{dt}.csv"))
+        for k, v in per_kernel(f).items():
+            if not k.startswith("k_"):
+                continue
+            for cn, val in v.items():
+                kern[k][cn if cn not in ("FETCH_SIZE", "WRITE_SIZE") else cn + "_KB"] = val
+    es = 4 if dt == "float32" else 8
+    for k, v in kern.items():
+        v["in_step"] = k != "k_econv"
+        # dominant access width of each kernel's HBM streams (spart_kernels.h): the prelude reads 8 B/lane parameter
+        # columns and writes 4 / 8 B/lane constant rows; the band kernel reads 128-B constant segments and writes
+        # the 4-B / 8-B per-lane band sums (+ 16-B G rows in float64 mode); the slot pass and the sensor kernel read
+        # 8 B/lane rows and write 8 B / dtype-sized columns
+        if k.startswith("k_prelude"):
+            fr, fw = corr("r", 8), corr("w", 8)
+        elif k.startswith("k_bands"):
+            fr, fw = (corr("r", "seg") if es == 4 else corr("r", 8)), corr("w", es)
+        elif k.startswith("k_slots"):
+            fr, fw = corr("r", 8), corr("w", 8)
+        else:
+            fr, fw = corr("r", 8), corr("w", es)
+        v["fetch_bytes"] = v.get("FETCH_SIZE_KB", 0.0) * 1024 / fr
+        v["write_bytes"] = v.get("WRITE_SIZE_KB", 0.0) * 1024 / fw
+        v["hbm_bytes"] = v["fetch_bytes"] + v["write_bytes"]
+        v["calibration"] = {"fetch": fr, "write": fw}
+    out = {"src_hash": src_hash(), "batch": 1_000_000, "nb": 13, "sensor": "Sentinel2A-MSI", "dtype": dt,
+           "command": f"rocprofv3 --kernel-trace --pmc <FETCH_SIZE | WRITE_SIZE | SQ set> -- python3 bench.py --steps 3 --warmup 1 "
+                      f"--dtype {dt} --cpu-rows 0 --no-extras  (three separate passes, tools/collect_profiles.sh {tag})",
+           "correction": "FETCH_SIZE / WRITE_SIZE (KB x 1024) divided by the factor measured on 1 GiB moved with the same "
+                         f"access width (profiles/{tag}_counter_calibration.json; MI355X_MICROARCH.md, HBM: gfx950 tallies wide "
+                         "reads at 1/2); Infinity-Cache hits are counted as traffic",
+           "kernels": kern}
+    json.dump(out, open(os.path.join(dst, f"{prefix}_counters_{dt}.json"), "w"), indent=1)
+    f = one(f"stats_{dt}/*/*_kernel_stats.csv")
+    if f:
+        shutil.copy(f, os.path.join(dst, f"{tag}_kernel_stats_{dt}.csv"))
+    print(dt, {k: (round(v["hbm_bytes"] / 1e6, 1), round(v.get("SQ_INSTS_VALU", 0) / 1e9, 3)) for k, v in kern.items()})
+
+# ---- config 2 (PROSPECT-only kernel at 10k x 2001 float64)
+c2 = {}
+for d in ("fetch", "write", "sq"):
+    f = one(f"c2_pmc_{d}/*/*_counter_collection.csv")
+    if f:
+        shutil.copy(f, os.path.join(dst, f"{tag}_c2_pmc_{d}.csv"))
+        for k, v in per_kernel(f).items():
+            if k.startswith("k_"):
+                c2.setdefault(k, {}).update(v)
+f = one("c2_stats/*/*_kernel_stats.csv")
+if f:
+    shutil.copy(f, os.path.join(dst, f"{tag}_c2_kernel_stats.csv"))
+if c2:
+    json.dump({"src_hash": src_hash(), "batch": 10_000, "kernels": c2,
+               "_note": "per launch, BASELINE config 2 (tools/prospect_bench.py 10000 float64); FETCH_SIZE / WRITE_SIZE in KB as reported"},
+              open(os.path.join(dst, f"{tag}_c2_counters.json"), "w"), indent=1)
+for name in ("bench.json", "c2_bench.txt"):
+    if os.path.exists(os.path.join(src, name)):
+        shutil.copy(os.path.join(src, name), os.path.join(dst, f"{tag}_{name}"))
+print(json.dumps(calib, indent=1))
