@@ -143,6 +143,38 @@ template <> struct Mx<float> {
 };
 
 #if defined(__HIPCC__)
+// Coefficient tables in constant memory are read through a pointer the optimiser cannot prove loop-invariant
+// (SPART_FRESH): left alone, hipcc hoists all 48 float64 coefficients of the band path (96 SGPRs) out of the sample
+// loop, runs out of SGPRs and parks them in VGPR lanes -- 32 v_readlane / v_writelane per band and sample in
+// k_prospect<double>, 16 % of its VALU instructions.  Reloaded per use they cost a few wide scalar loads (scalar
+// cache) and no VALU slot.
+#ifndef SPART_FRESH_COEF
+#define SPART_FRESH_COEF 1
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const double __attribute__((address_space(4))) * spart_cdp;   // constant address space: uniform loads stay scalar
+#else
+typedef const double* spart_cdp;
+#endif
+__device__ __forceinline__ spart_cdp spart_fresh(const double* p) {
+  spart_cdp q = (spart_cdp)p;
+#if SPART_FRESH_COEF && defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+s"(q));
+#endif
+  return q;
+}
+// One Horner step p * x + c with the coefficient c taken from an SGPR pair as the ADDEND of a three-address
+// v_fma_f64.  Written as C++, hipcc selects the two-address v_fmac_f64 (which overwrites its addend) and first copies
+// every coefficient into a VGPR pair: two v_mov_b32 per step, 138 of 467 VALU instructions in k_prospect<double>.
+__device__ __forceinline__ double spart_horner(double p, double x, double c_uniform) {
+#if defined(__HIP_DEVICE_COMPILE__) && SPART_FRESH_COEF
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(p), "v"(x), "s"(c_uniform));
+  return d;
+#else
+  return __builtin_fma(p, x, c_uniform);
+#endif
+}
 // exp / log for the float64 band arithmetic (device, SPART_FAST_MATH): the usual range reductions with their polynomial
 // coefficients in constant memory (scalar loads -> SGPR operands, no VGPRs parked on constants, no copy before each
 // Horner step as with the library versions).  exp(x) is 0 below x = -745 (including -inf), NaN
@@ -160,9 +192,10 @@ template <> struct Mx<double> {
     const double k = __builtin_rint(x * inv_ln_b);
     double r = __builtin_fma(-k, ln_b_hi, x);
     r = __builtin_fma(-k, ln_b_lo, r);
-    double p = c_EXP_F64[11];
+    spart_cdp ce = spart_fresh(c_EXP_F64);
+    double p = ce[11];
 #pragma unroll
-    for (int i = 10; i >= 0; --i) p = __builtin_fma(p, r, c_EXP_F64[i]);
+    for (int i = 10; i >= 0; --i) p = spart_horner(p, r, ce[i]);
     p = __builtin_fma(p * r, r, r);                       // r + r^2 (1/2 + ...)
     return __builtin_ldexp(1.0 + p, (int)k);
   }
@@ -172,9 +205,10 @@ template <> struct Mx<double> {
   static SPART_HD double exp2(double x) {                  // 2^x = e^(x ln 2)
     const double k = __builtin_rint(x);
     const double r = (x - k) * 0.6931471805599453;
-    double p = c_EXP_F64[11];
+    spart_cdp ce = spart_fresh(c_EXP_F64);
+    double p = ce[11];
 #pragma unroll
-    for (int i = 10; i >= 0; --i) p = __builtin_fma(p, r, c_EXP_F64[i]);
+    for (int i = 10; i >= 0; --i) p = spart_horner(p, r, ce[i]);
     p = __builtin_fma(p * r, r, r);
     return __builtin_ldexp(1.0 + p, (int)k);
   }
@@ -184,9 +218,10 @@ template <> struct Mx<double> {
     double m = __builtin_frexp(x, &e);                     // m in [0.5, 1)
     if (m < 0.7071067811865476) { m *= 2.0; e -= 1; }
     const double s = (m - 1.0) * rcp(m + 1.0), s2 = s * s;
-    double p = c_LOG_F64[8];
+    spart_cdp cl = spart_fresh(c_LOG_F64);
+    double p = cl[8];
 #pragma unroll
-    for (int i = 7; i >= 0; --i) p = __builtin_fma(p, s2, c_LOG_F64[i]);
+    for (int i = 7; i >= 0; --i) p = spart_horner(p, s2, cl[i]);
     p = __builtin_fma(p * s2, s, s);                       // s + s^3 (1/3 + ...)
     const double ed = (double)e;
     return __builtin_fma(ed, 6.93147180369123816490e-01, __builtin_fma(ed, 1.90821492927058770002e-10, 2.0 * p));
@@ -311,9 +346,9 @@ template <typename T> SPART_HD T sail_j2_d(T L, T tk, T e1, T kpm, T ikpm) {
 template <typename T> struct E3c;
 template <> struct E3c<float> {
   static constexpr int GD = E3_G_DEG_F32, WD = E3_W_DEG_F32;
-  static SPART_HD float g(int i) { return E3_G_F32[i]; }
-  static SPART_HD float p(int i) { return E3_P_F32[i]; }
-  static SPART_HD float q(int i) { return E3_Q_F32[i]; }
+  static SPART_HD const float* gt() { return E3_G_F32; }     // (instruction literals after unrolling)
+  static SPART_HD const float* pt() { return E3_P_F32; }
+  static SPART_HD const float* qt() { return E3_Q_F32; }
 };
 #if defined(__HIPCC__)
 // The 27 float64 coefficients of the plate transmittance live in constant memory on the device: they arrive through
@@ -332,15 +367,22 @@ __device__ __constant__ double c_E3_Q_F64[7] = SPART_L7(E3_Q_F64);
 template <> struct E3c<double> {
   static constexpr int GD = E3_G_DEG_F64, WD = E3_W_DEG_F64;
 #if defined(__HIP_DEVICE_COMPILE__)
-  static SPART_HD double g(int i) { return c_E3_G_F64[i]; }
-  static SPART_HD double p(int i) { return c_E3_P_F64[i]; }
-  static SPART_HD double q(int i) { return c_E3_Q_F64[i]; }
+  static SPART_HD spart_cdp gt() { return spart_fresh(c_E3_G_F64); }
+  static SPART_HD spart_cdp pt() { return spart_fresh(c_E3_P_F64); }
+  static SPART_HD spart_cdp qt() { return spart_fresh(c_E3_Q_F64); }
 #else
-  static SPART_HD double g(int i) { return E3_G_F64[i]; }
-  static SPART_HD double p(int i) { return E3_P_F64[i]; }
-  static SPART_HD double q(int i) { return E3_Q_F64[i]; }
+  static SPART_HD const double* gt() { return E3_G_F64; }
+  static SPART_HD const double* pt() { return E3_P_F64; }
+  static SPART_HD const double* qt() { return E3_Q_F64; }
 #endif
 };
+
+#if defined(__HIPCC__)
+SPART_HD double horner_step(double p, double x, double c) { return spart_horner(p, x, c); }
+#else
+SPART_HD double horner_step(double p, double x, double c) { return p * x + c; }
+#endif
+SPART_HD float horner_step(float p, float x, float c) { return p * x + c; }
 
 template <typename T> SPART_HD void plate_tau(T K, T& tau, T& u) {
   using C = E3c<T>;
@@ -351,18 +393,20 @@ template <typename T> SPART_HD void plate_tau(T K, T& tau, T& u) {
   const bool small = x < T(1);
   T v;  // u on the small branch, tau on the large one (one value, so nothing is spilled to select them)
   if (small) {
-    T g = C::g(C::GD);
+    const auto cg = C::gt();
+    T g = cg[C::GD];
 #pragma unroll
-    for (int i = C::GD - 1; i >= 0; --i) g = g * x + C::g(i);
+    for (int i = C::GD - 1; i >= 0; --i) g = horner_step(g, x, cg[i]);
     v = x * (g + x * Mx<T>::log(x));
   } else {
     // P(t)/Q(t) with t = 1/x, written in x (coefficients reversed) so that a single reciprocal is needed:
     // tau = e^-x * 2 Pr(x) / ((x + 3) Qr(x)),  Pr(x) = x^n P(1/x)
-    T pn = T(2) * C::p(0), qn = C::q(0);   // (the factor 2 is folded into P's constants: exact)
+    const auto cp = C::pt(), cq = C::qt();
+    T pn = T(2) * cp[0], qn = cq[0];       // (the factor 2 is folded into P's constants: exact)
 #pragma unroll
     for (int i = 1; i <= C::WD; ++i) {
-      pn = pn * x + T(2) * C::p(i);
-      qn = qn * x + C::q(i);
+      pn = horner_step(pn, x, T(2) * cp[i]);
+      qn = horner_step(qn, x, cq[i]);
     }
     v = Mx<T>::exp(-x) * pn * Mx<T>::rcp((x + T(3)) * qn);
   }
@@ -416,15 +460,15 @@ template <typename T> struct BandTab {
 enum ConstIdx {
   // leaf: concentrations already divided by N (prospect_5d.py:170-179)
   C_CAB = 0, C_CCA, C_CDM, C_CW, C_CS, C_CANT, C_CBC, C_PROT, C_NM1, C_RHO_TH, C_TAU_TH,
-  // soil (bsm.py:49-52, 101, 121-122)
-  C_F1, C_F2, C_F3, C_WET, C_FM0, C_FM1, C_FM2, C_FM3, C_FM4, C_FM5, C_FM6, C_FILM2,
-  // canopy (sailh.py:93-105, 200-203, 216, 219)
-  C_SDB, C_SDF, C_DDB, C_DDF, C_DOB, C_DOF, C_SOB, C_SOF, C_BF, C_KS, C_KO, C_LAI,
-  C_TSS, C_TOO, C_Z, C_HOT, C_PSO2W,
-  C_FMSUM, C_HBF, C_LAI2, C_FILM2L, C_RSV4, C_RSV5, C_RSV6, C_RSV7,
-  NCONST  // 48
+  // soil (bsm.py:49-52, 101, 121-122): GSV factors, wet flag, Poisson weights and their sum, 2 film log2(e)
+  C_F1, C_F2, C_F3, C_WET, C_FM0, C_FM1, C_FM2, C_FM3, C_FM4, C_FM5, C_FM6, C_FMSUM, C_FILM2L,
+  // canopy (sailh.py:93-97, 200-203, 216, 219); the six geometric factors of sailh.py:100-105 are (k +- bf)/2,
+  // (1 +- bf)/2, (K +- bf)/2 and are formed from ks, ko, bf/2 where they are used (canopy_core)
+  C_SOB, C_SOF, C_HBF, C_KS, C_KO, C_LAI, C_LAI2, C_TSS, C_TOO, C_Z, C_HOT, C_PSO2W,
+  C_RSV0, C_RSV1, C_RSV2, C_RSV3,
+  NCONST  // 40: 36 used, padded to a multiple of 8 (stage_constants)
 };
-static_assert(NCONST == 48, "constant block is 48 values");
+static_assert(NCONST == 40, "constant block is 40 values");
 
 // per-sample atmosphere scalars (double), read by the sensor-band kernel
 enum AtmIdx {
@@ -929,7 +973,6 @@ SPART_HD void sample_prelude_to(const In& in /* in(i) = parameter i of 27, read 
     }
     out.c(C_FMSUM, fsum);
   }
-  out.c(C_FILM2, 2.0 * film);
   out.c(C_FILM2L, 2.0 * film * 1.4426950408889634);
   }
   double tts = in(19), tto = in(20), rel = in(21);
@@ -960,15 +1003,8 @@ SPART_HD void sample_prelude_to(const In& in /* in(i) = parameter i of 27, read 
     sob += frho * PI / (cos_tts * cos_tto) * li;                                              // :88, 96
     sof += ftau * PI / (cos_tts * cos_tto) * li;                                              // :89, 97
   }
-  out.c(C_SDB, 0.5 * (ks + bf));  // :100-105
-  out.c(C_SDF, 0.5 * (ks - bf));
-  out.c(C_DDB, 0.5 * (1.0 + bf));
-  out.c(C_DDF, 0.5 * (1.0 - bf));
-  out.c(C_DOB, 0.5 * (ko + bf));
-  out.c(C_DOF, 0.5 * (ko - bf));
   out.c(C_SOB, sob);
   out.c(C_SOF, sof);
-  out.c(C_BF, bf);
   out.c(C_HBF, 0.5 * bf);
   out.c(C_KS, ks);
   out.c(C_KO, ko);

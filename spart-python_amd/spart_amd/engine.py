@@ -144,15 +144,16 @@ class Engine:
         return buf
 
     # ------------------------------------------------------------------ operators
-    def prospect(self, leaf9, dtype="float64"):
-        """PROSPECT_5D for a batch (prospect_5d.py:117-246): leaf9 = [Cab,Cdm,Cw,Cs,Cca,Cant,N,PROT,CBC]."""
+    def prospect(self, leaf9, dtype="float64", outputs=("refl", "tran", "kChlrel")):
+        """PROSPECT_5D for a batch (prospect_5d.py:117-246): leaf9 = [Cab,Cdm,Cw,Cs,Cca,Cant,N,PROT,CBC].
+        -> [refl, tran, kChlrel], each (B, 2001); entries not named in ``outputs`` are None (not computed / stored)."""
         dt = DTYPES[dtype]
         cols, B = self.columns(leaf9)
         td = self._tdtype(dt)
-        out = [self._alloc_spec(B, _lib.NWL, td) for _ in range(3)]
+        out = [self._alloc_spec(B, _lib.NWL, td) if n in outputs else None for n in ("refl", "tran", "kChlrel")]
         ws, wsn = self._workspace(dt, B)
-        rc = self.lib.spart_prospect_batch(self.ctx, dt, B, self._ptrs(cols), out[0].data_ptr(), out[1].data_ptr(),
-                                           out[2].data_ptr(), ws, wsn, self._stream())
+        rc = self.lib.spart_prospect_batch(self.ctx, dt, B, self._ptrs(cols), *[o.data_ptr() if o is not None else None for o in out],
+                                           ws, wsn, self._stream())
         _lib.check(self.lib, self.ctx, rc)
         return out
 

@@ -6,7 +6,7 @@ import sys
 from collections import defaultdict
 
 d = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(__file__), "..", "gpurun_out", "pmc_ab")
-kern = sys.argv[2] if len(sys.argv) > 2 else "k_bands<float, false, true>"
+kern = sys.argv[2] if len(sys.argv) > 2 else "k_bands<float, 0, 1, false>"
 for f in sorted(glob.glob(os.path.join(d, "p*.csv"))):
     rows = defaultdict(dict)            # dispatch id -> counter -> value
     for r in csv.DictReader(open(f)):
