@@ -9,6 +9,7 @@ On-disk layout (a directory):
     R_TOC.npy / R_TOA.npy / L_TOA.npy   (B, nb) in the chosen dtype
 All .npy files are plain numpy arrays (np.load(..., mmap_mode="r") works for tables larger than RAM).
 """
+import ctypes
 import json
 import os
 
@@ -19,8 +20,28 @@ from .engine import get_engine
 
 COLUMNS = ("R_TOC", "R_TOA", "L_TOA")
 
+_MADV_POPULATE_WRITE = 23          # linux/mman.h (Linux >= 5.14): fault the range in, writable, inside ONE system call
+_libc = None
 
-def generate_lut(params, sensor, path=None, dtype="float32", chunk=1 << 20, device=None, prune=False):
+
+def _prefault(a):
+    """Make the pages under the C-contiguous numpy view ``a`` resident and writable without touching their contents.
+    The destination of a LUT is fresh memory (1.25 GB per 8M Sentinel-2 spectra): left to the download copies, its
+    first-touch page faults -- zero-filling 4 KB at a time on the copying thread -- cost more than the kernels that
+    produce the data.  Several threads call this on disjoint slices ahead of the pipeline (ctypes releases the GIL).
+    Returns False where the kernel does not know MADV_POPULATE_WRITE (then the copies fault the pages in as before)."""
+    global _libc
+    if a.nbytes == 0:
+        return True
+    if _libc is None:
+        _libc = ctypes.CDLL(None, use_errno=True)
+        _libc.madvise.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    page = os.sysconf("SC_PAGE_SIZE")
+    lo = a.ctypes.data & ~(page - 1)
+    return _libc.madvise(lo, a.ctypes.data + a.nbytes - lo, _MADV_POPULATE_WRITE) == 0
+
+
+def generate_lut(params, sensor, path=None, dtype="float32", chunk=1 << 20, device=None, prune=False, fault_threads=8):
     """params: (B, 27) array-like on the HOST (numpy / memmap).  Returns dict of host arrays (np.memmap when
     ``path`` is given).  ``prune=True`` evaluates only the bands the sensor needs (identical columns).
 
@@ -30,9 +51,11 @@ def generate_lut(params, sensor, path=None, dtype="float32", chunk=1 << 20, devi
         launch(i+1)   queued behind chunk i on the compute stream
         download(i)   D2H of the three (n, nb) column blocks straight into the destination arrays / memmaps
                                                                             -- overlaps the kernels of chunk i+1
+        prefault(i+2) ``fault_threads`` helper threads make the destination pages of chunk i+2 resident (see _prefault)
     The copies block the HOST thread (pageable memory) but not the GPU, which stays busy as long as the two copies
     of a chunk (372 B per spectrum, ~7 ms per 1M at PCIe Gen5 rates) take less than its kernels (12 ms per 1M)."""
     import warnings
+    from concurrent.futures import ThreadPoolExecutor
 
     import torch
 
@@ -98,9 +121,23 @@ def generate_lut(params, sensor, path=None, dtype="float32", chunk=1 << 20, devi
         eng.run(Pd, dtype, out={"R_TOC": res[0], "R_TOA": res[1], "L_TOA": res[2]}, prune=prune)
         ev_done[j].record(compute)
 
+    fault_threads = max(0, int(fault_threads))
+    fpool = ThreadPoolExecutor(fault_threads) if fault_threads else None
+    faults = {}                                                    # chunk -> futures of its prefault tasks
+
+    def prefault(i):
+        if fpool is None or i >= nchunks or i in faults:
+            return
+        lo, n = bounds(i)
+        dests = [out[k][lo:lo + n] for k in COLUMNS] + ([pm[lo:lo + n]] if pm is not None else [])
+        per = max(1, -(-n // max(1, fault_threads // len(dests))))
+        faults[i] = [fpool.submit(_prefault, d[r:r + per]) for d in dests for r in range(0, n, per)]
+
     def download(i):                                               # runs on the helper thread
         j = i % 2
         lo, n = bounds(i)
+        for f in faults.pop(i, ()):
+            f.result()                                             # the destination pages of this chunk are resident
         with torch.cuda.device(dev), torch.cuda.stream(d2h):
             d2h.wait_event(ev_done[j])
             for q, k in enumerate(COLUMNS):
@@ -109,13 +146,15 @@ def generate_lut(params, sensor, path=None, dtype="float32", chunk=1 << 20, devi
 
     # downloads (which also take the first-touch page faults of the destination) run on one helper thread so that
     # they overlap the uploads issued by this thread; torch releases the GIL inside the copies
-    from concurrent.futures import ThreadPoolExecutor
     fut = [None, None]
     with ThreadPoolExecutor(1) as pool:
+        prefault(0)
+        prefault(1)
         if nchunks:
             upload(0)
             launch(0)
         for i in range(nchunks):
+            prefault(i + 2)
             if i + 1 < nchunks:
                 upload(i + 1)                                      # overlaps the kernels of chunk i
                 if fut[(i + 1) % 2] is not None:
@@ -125,6 +164,8 @@ def generate_lut(params, sensor, path=None, dtype="float32", chunk=1 << 20, devi
         for f in fut:
             if f is not None:
                 f.result()
+    if fpool is not None:
+        fpool.shutdown()
     if path is not None:
         for a in out.values():
             a.flush()
