@@ -685,6 +685,7 @@ SPART_HD double lidf_dcum(double a, double b, double theta_deg) {
 SPART_HD double lidf_theta(int i);
 SPART_HD double lidf_sin_2theta(int i);
 SPART_HD double lidf_cos_2theta(int i);
+SPART_HD void lidf_sincos(double u, double s2, double c2, double& sn, double& cs);
 SPART_HD double lidf_dcum_newton(double a, double b, int i) {
   const double theta_deg = lidf_theta(i);
   if (!(::fabs(a) + ::fabs(b) < 0.95)) return lidf_dcum(a, b, theta_deg);
@@ -699,28 +700,8 @@ SPART_HD double lidf_dcum_newton(double a, double b, int i) {
   const double s2 = lidf_sin_2theta(i), c2 = lidf_cos_2theta(i);
   double y = s2 * (a + b * c2);
   for (int it = 0; it < 12; ++it) {
-    const double y2 = y * y;
-    double ps = -1.0 / 121645100408832000.0;            // sin y / y:  ... - y^18/19!
-    ps = ps * y2 + 1.0 / 355687428096000.0;
-    ps = ps * y2 - 1.0 / 1307674368000.0;
-    ps = ps * y2 + 1.0 / 6227020800.0;
-    ps = ps * y2 - 1.0 / 39916800.0;
-    ps = ps * y2 + 1.0 / 362880.0;
-    ps = ps * y2 - 1.0 / 5040.0;
-    ps = ps * y2 + 1.0 / 120.0;
-    ps = ps * y2 - 1.0 / 6.0;
-    ps = ps * y2 + 1.0;
-    double pc = 1.0 / 6402373705728000.0;                // cos y:  ... + y^18/18!
-    pc = pc * y2 - 1.0 / 20922789888000.0;
-    pc = pc * y2 + 1.0 / 87178291200.0;
-    pc = pc * y2 - 1.0 / 479001600.0;
-    pc = pc * y2 + 1.0 / 3628800.0;
-    pc = pc * y2 - 1.0 / 40320.0;
-    pc = pc * y2 + 1.0 / 720.0;
-    pc = pc * y2 - 1.0 / 24.0;
-    pc = pc * y2 + 0.5;
-    const double sy = y * ps, cy = 1.0 - y2 * pc;
-    const double sn = s2 * cy + c2 * sy, cs = c2 * cy - s2 * sy;   // sin x, cos x
+    double sn, cs;
+    lidf_sincos(y, s2, c2, sn, cs);                                // sin x, cos x
     const double f = y - sn * (a + b * cs);
     const double fp = 1.0 - a * cs - b * (2.0 * cs * cs - 1.0);
     const double d = f / fp;
@@ -735,48 +716,146 @@ SPART_HD double lidf_theta(int i) { return (i < 8) ? 10.0 * (i + 1) : 80.0 + 2.0
 // litab: 5,15,...,75,81,83,...,89                                  (sailh.py:49)
 SPART_HD double lidf_litab(int i) { return (i < 8) ? 5.0 + 10.0 * i : 81.0 + 2.0 * (i - 8); }
 
-// The literal iteration again (the reference's stopping rule and iterates), but in the small unknown u = x - 2 theta:
-//   x <- x + 1/2 (y - x + 2 theta)   ==   u <- u + 1/2 (y - u),   y = sin x (a + b cos x),
-// with sin x, cos x from the angle-addition formulas with the tabulated (sin, cos)(2 theta) and the Taylor polynomials
-// of sin u, cos u (to u^19 / u^18; |u| <= |a| + |b|/2 <= 1: 1/21! = 2e-20), i.e. ~30 multiply-adds per step instead
-// of a library sincos with its argument reduction.  The iterates differ from the x-form's by rounding (1e-16) only.
-// |a| + |b|/2 > 1 (non-physical) and a > 1 keep the library form.
-SPART_HD double lidf_dcum_lit(double a, double b, int i) {
+// sin x, cos x for x = 2 theta + u from the angle-addition formulas with the tabulated (sin, cos)(2 theta) = (s2, c2)
+// and the Taylor polynomials of sin u, cos u (to u^19 / u^18; |u| <= 1: 1/21! = 2e-20): ~25 multiply-adds instead of a
+// library sincos with its argument reduction
+SPART_HD void lidf_sincos(double u, double s2, double c2, double& sn, double& cs) {
+  const double u2 = u * u;
+  double ps = -1.0 / 121645100408832000.0;            // sin u / u:  ... - u^18/19!
+  ps = ps * u2 + 1.0 / 355687428096000.0;
+  ps = ps * u2 - 1.0 / 1307674368000.0;
+  ps = ps * u2 + 1.0 / 6227020800.0;
+  ps = ps * u2 - 1.0 / 39916800.0;
+  ps = ps * u2 + 1.0 / 362880.0;
+  ps = ps * u2 - 1.0 / 5040.0;
+  ps = ps * u2 + 1.0 / 120.0;
+  ps = ps * u2 - 1.0 / 6.0;
+  ps = ps * u2 + 1.0;
+  double pc = 1.0 / 6402373705728000.0;                // (1 - cos u) / u^2:  1/2 - u^2/24 + ... + u^16/18!
+  pc = pc * u2 - 1.0 / 20922789888000.0;
+  pc = pc * u2 + 1.0 / 87178291200.0;
+  pc = pc * u2 - 1.0 / 479001600.0;
+  pc = pc * u2 + 1.0 / 3628800.0;
+  pc = pc * u2 - 1.0 / 40320.0;
+  pc = pc * u2 + 1.0 / 720.0;
+  pc = pc * u2 - 1.0 / 24.0;
+  pc = pc * u2 + 0.5;
+  const double su = u * ps, cu = 1.0 - u2 * pc;
+  sn = s2 * cu + c2 * su;
+  cs = c2 * cu - s2 * su;
+}
+
+// The literal iteration (the reference's stopping rule and iterates, sailh.py:378-382) in the small unknown
+// u = x - 2 theta:   x <- x + 1/2 (y - x + 2 theta)   ==   u <- u + g(u),  g(u) = 1/2 (y(u) - u),
+// y(u) = sin x (a + b cos x).  The iterates differ from the x-form's by rounding (1e-16) only.
+// |a| + |b|/2 > 1 (non-physical) and a > 1 keep the library form (lidf_dcum).
+//
+// JUMP: the iteration converges linearly, e_{n+1} = phi(e_n) = r e_n + c2 e_n^2 + ..., e = u - u*, with
+// r = (1 + y'(u*))/2 up to 0.9 in the usual parameter ranges, i.e. 30 ... 170 steps down to |g| <= 1e-8 -- the
+// largest single cost of the float64 prelude.  Once an iterate is close to the fixed point the rest of the
+// trajectory is known in closed form: with the Koenigs function h(e) = e + a2 e^2 + a3 e^3 + a4 e^4,
+// h(phi(e)) = r h(e), every later iterate is e_{m+k} = h^-1(r^k h(e_m)).  So: iterate literally until the expansion
+// parameter c2max |e| / (r (1 - r)) is below 5e-3 (truncation below 1e-9 relative), find u* by Newton, evaluate
+// r, c2, c3, c4 from the derivatives of y there, find the FIRST k with |g(u_{m+k})| <= 1e-8 -- the reference's
+// stopping index -- and return the reference's F = (2 y(u_{m+k}) + 2 theta)/pi at that iterate.  The result differs
+// from the literally iterated one by ~1e-15 (the CPU-side arithmetic tests compare the two over the reference's whole LIDF
+// grid); lanes with r outside [0.3, 0.98], or whose Newton step does not settle, simply finish the literal loop.
+// The jump itself costs about nine literal steps (three Newton steps, five reciprocals, r^k by binary descent over
+// r^(2^j) -- no logarithm, no exponential).
+template <bool JUMP> SPART_HD double lidf_dcum_lit_impl(double a, double b, int i, int* jumped = nullptr) {
   if (!(::fabs(a) + 0.5 * ::fabs(b) <= 1.0)) return lidf_dcum(a, b, lidf_theta(i));
   const double rd = PI / 180.0;
   const double theta2 = 2.0 * rd * lidf_theta(i);
   const double s2 = lidf_sin_2theta(i), c2 = lidf_cos_2theta(i);
-  double u = 0.0, y, dx;
+  const double kjump = 5e-3 / (0.25 * (::fabs(a) + 2.0 * ::fabs(b)) + 0.02);   // 5e-3 / (bound of |y''| / 4, + margin)
+  double u = 0.0, y, dx = 0.0, dprev;
+  bool more, ready = false;
   int it = 0;
-  do {  // sailh.py:378-382
-    const double u2 = u * u;
-    double ps = -1.0 / 121645100408832000.0;            // sin u / u:  ... - u^18/19!
-    ps = ps * u2 + 1.0 / 355687428096000.0;
-    ps = ps * u2 - 1.0 / 1307674368000.0;
-    ps = ps * u2 + 1.0 / 6227020800.0;
-    ps = ps * u2 - 1.0 / 39916800.0;
-    ps = ps * u2 + 1.0 / 362880.0;
-    ps = ps * u2 - 1.0 / 5040.0;
-    ps = ps * u2 + 1.0 / 120.0;
-    ps = ps * u2 - 1.0 / 6.0;
-    ps = ps * u2 + 1.0;
-    double pc = 1.0 / 6402373705728000.0;                // (1 - cos u) / u^2:  1/2 - u^2/24 + ... + u^16/18!
-    pc = pc * u2 - 1.0 / 20922789888000.0;
-    pc = pc * u2 + 1.0 / 87178291200.0;
-    pc = pc * u2 - 1.0 / 479001600.0;
-    pc = pc * u2 + 1.0 / 3628800.0;
-    pc = pc * u2 - 1.0 / 40320.0;
-    pc = pc * u2 + 1.0 / 720.0;
-    pc = pc * u2 - 1.0 / 24.0;
-    pc = pc * u2 + 0.5;
-    const double su = u * ps, cu = 1.0 - u2 * pc;
-    const double sn = s2 * cu + c2 * su, cs = c2 * cu - s2 * su;   // sin x, cos x
+  // literal phase: a lane leaves when it has converged (the reference's test) or is close enough to jump; the lanes of
+  // a wave reconverge behind the loop, so the jump below runs once per wave
+  do {
+    double sn, cs;
+    dprev = dx;
+    u += dx;                               // (the step found in the previous pass; 0 in the first)
+    lidf_sincos(u, s2, c2, sn, cs);
     y = sn * (a + b * cs);
     dx = 0.5 * (y - u);
+    more = ::fabs(dx) > 1e-8;              // sailh.py:382 -- y belongs to the iterate BEFORE the update
+    if (JUMP && ::fabs(dx) < 4e-3) {
+      // rho = dx / dprev estimates r; ready when 0.3 < rho < 0.98 and |dx| < 5e-3 rho (1 - rho)^2 / c2max, written
+      // without the division: |dprev|^3 < K (|dprev| - |dx|)^2
+      const double ad = ::fabs(dx), ap = ::fabs(dprev), df = ap - ad;
+      ready = dx * dprev > 0.0 && ad > 0.3 * ap && ad < 0.98 * ap && ap * ap * ap < kjump * (df * df);
+    }
+  } while (more && !ready && ++it < 100000);
+  if (JUMP && more && ready) {
+    // state: iterate u_m = u with g(u_m) = dx (not yet applied), previous step dprev
+    using Md = Mx<double>;
+    double us = u + dx * dprev * Md::rcp(dprev - dx);   // u + dx / (1 - rho): geometric extrapolation of the fixed point
+    double sn, cs, nstep = 1.0;
+    for (int k = 0; k < 3; ++k) {          // Newton on g(u) = 0: 1e-5 -> 1e-9 -> 1e-17
+      lidf_sincos(us, s2, c2, sn, cs);
+      const double f = sn * (a + b * cs) - us;                            // 2 g
+      const double fp = a * cs + b * (2.0 * cs * cs - 1.0) - 1.0;         // 2 g'
+      nstep = f * Md::rcp(fp);
+      us -= nstep;
+    }
+    lidf_sincos(us, s2, c2, sn, cs);
+    const double s2x = 2.0 * sn * cs, c2x = 2.0 * cs * cs - 1.0;          // sin 2x, cos 2x at the fixed point
+    const double y1 = a * cs + b * c2x, y2 = -a * sn - 2.0 * b * s2x, y3 = -a * cs - 4.0 * b * c2x, y4 = a * sn + 8.0 * b * s2x;
+    const double r = 0.5 * (1.0 + y1), q2 = 0.25 * y2, q3 = y3 * (1.0 / 12.0), q4 = y4 * (1.0 / 48.0);
+    const double r2 = r * r;
+    const double i1 = Md::rcp(r - r2);                                    // 1 / (r (1 - r))
+    const double a2 = q2 * i1;
+    const double a3 = (q3 + 2.0 * a2 * r * q2) * i1 * Md::rcp(1.0 + r);             // / (r - r^3)
+    const double a4 = (q4 + a2 * (q2 * q2 + 2.0 * r * q3) + 3.0 * a3 * r2 * q2) * i1 * Md::rcp(1.0 + r + r2);   // / (r - r^4)
+    const double em = u - us;
+    const double hm = em * (1.0 + em * (a2 + em * (a3 + em * a4)));
+    const bool ok = r > 0.25 && r < 0.985 && ::fabs(a2 * em) < 0.02 && ::fabs(us) <= 1.0 && ::fabs(nstep) < 1e-12;
+    if (ok) {
+      // largest k with (1 - r) |h_m| r^k > 1e-8 (leading order of |g(u_{m+k})|) by binary descent over r^(2^j): the
+      // stopping index is k + 1 up to the higher-order terms, which the three candidates below settle
+      double pw[9];
+      pw[0] = r;
+      for (int j = 1; j < 9; ++j) pw[j] = pw[j - 1] * pw[j - 1];
+      double G = (1.0 - r) * ::fabs(hm), rk = 1.0;
+      for (int j = 8; j >= 0; --j) {
+        const bool take = G * pw[j] > 1e-8;
+        G = take ? G * pw[j] : G;
+        rk = take ? rk * pw[j] : rk;
+      }
+      const double b3 = 2.0 * a2 * a2 - a3;
+      double H = hm * rk, ek = 0.0;        // k: still above the threshold at leading order; then k + 1, k + 2
+      bool found = false;
+      for (int c = 0; c < 3; ++c) {
+        const double e = H * (1.0 - H * (a2 - H * b3));                  // h^-1(H)
+        const double g = e * ((r - 1.0) + e * (q2 + e * q3));              // g(u* + e)
+        const bool hit = !found && !(::fabs(g) > 1e-8);
+        ek = hit ? e : ek;
+        found = found || hit;
+        H *= r;
+      }
+      if (found) {
+        y = us + ek * ((2.0 * r - 1.0) + ek * (0.5 * y2 + ek * (y3 * (1.0 / 6.0))));   // y(u* + e), y(u*) = u*
+        more = false;
+        if (jumped) *jumped = 1;
+      }
+    }
+  }
+  while (more && ++it < 100000) {           // lanes that did not jump: the rest of the literal iteration
+    double sn, cs;
     u += dx;
-  } while (::fabs(dx) > 1e-8 && ++it < 100000);
+    lidf_sincos(u, s2, c2, sn, cs);
+    y = sn * (a + b * cs);
+    dx = 0.5 * (y - u);
+    more = ::fabs(dx) > 1e-8;
+  }
   return (2.0 * y + theta2) / PI;
 }
+#ifndef SPART_LIDF_JUMP
+#define SPART_LIDF_JUMP 1
+#endif
+SPART_HD double lidf_dcum_lit(double a, double b, int i) { return lidf_dcum_lit_impl<(SPART_LIDF_JUMP != 0)>(a, b, i); }
 
 // sin / cos of the 13 class-centre inclinations litab(i) and of twice the 12 class boundaries theta(i): constants of
 // the model (sailh.py:49, 388-394), tabulated (math.sin / math.cos of the same double arguments) so that no sample

@@ -93,6 +93,20 @@ void hm_sensor(int64_t B, int nb, const double* atm, const double* coef, const d
     }
 }
 
+// cumulative LIDF at the 12 class boundaries: mode 0 = the reference's x-form with library sin / cos (lidf_dcum),
+// 1 = the same iteration in u with the Taylor rotation, 2 = with the closed-form jump over its linear tail;
+// jumped[i] = 1 where mode 2 took the jump
+void hm_lidf_dcum(int mode, int64_t n, const double* a, const double* b, double* F /* (n, 12) */, int* jumped /* (n, 12) */) {
+  for (int64_t s = 0; s < n; ++s)
+    for (int i = 0; i < NLINCL - 1; ++i) {
+      int j = 0;
+      double f = mode == 0 ? lidf_dcum(a[s], b[s], lidf_theta(i))
+                           : (mode == 1 ? lidf_dcum_lit_impl<false>(a[s], b[s], i) : lidf_dcum_lit_impl<true>(a[s], b[s], i, &j));
+      F[s * (NLINCL - 1) + i] = f;
+      jumped[s * (NLINCL - 1) + i] = j;
+    }
+}
+
 void hm_plate_tau(int dtype, int64_t n, const double* K, double* tau, double* u) {
   for (int64_t i = 0; i < n; ++i) {
     if (dtype == 0) { float t, uu; plate_tau<float>((float)K[i], t, uu); tau[i] = t; u[i] = uu; }

@@ -113,3 +113,32 @@ def test_hotspot_integrals_cover_small_q(hm, tab, oracle, tables):
     out, _, _, toa = run_chain(hm, tab, oracle, tables, P, "Sentinel2A-MSI", 1)
     assert rel_err(out[:, :, 5], ref["rso"][:, :2002], 1e-3) < 1e-8
     assert rel_err(toa[:, :, 0], ref["R_TOC"], 1e-3) < 1e-8
+
+
+def test_lidf_jump_reproduces_the_literal_iteration(hm, oracle):
+    """The cumulative LIDF of the float64 prelude: the reference's fixed-point iteration with its |dx| > 1e-8 stopping rule
+    (sailh.py:378-382), (0) in the x-form with library sin / cos, (1) in u = x - 2 theta with the Taylor rotation,
+    (2) with the closed-form jump over the linear tail of the iteration (Koenigs function).  All three must land on the
+    SAME iterate: over the benchmark ranges, the reference's own SAILH test grid (build_SAILH_tests.py:89-90, which
+    includes |a| + |b| > 1) and random pairs up to |a| + |b| = 1; and the jump must actually be taken in the usual
+    ranges (otherwise this test would compare the literal loop with itself)."""
+    rng = np.random.default_rng(7)
+    a = np.concatenate([rng.uniform(-0.5, 0.5, 3000), rng.uniform(-1, 1, 2000), np.repeat(np.arange(-1, 1, 0.4), 5),
+                        [0.0, -0.35, 0.5, -0.5, 0.999, -0.999, 0.0, 0.0]])
+    b = np.concatenate([rng.uniform(-0.3, 0.3, 3000), rng.uniform(-1, 1, 2000), np.tile(np.arange(-1, 1, 0.4), 5),
+                        [0.0, -0.15, 0.3, -0.3, 0.0, 0.0, 0.999, -0.999]])
+    keep = np.abs(a) + np.abs(b) <= 1.0 + 1e-12
+    keep[5000:5025] = True                                     # the reference grid as it is, non-physical pairs included
+    a, b = np.ascontiguousarray(a[keep]), np.ascontiguousarray(b[keep])
+    n = a.size
+    F = [np.zeros((n, 12)) for _ in range(3)]
+    J = [np.zeros((n, 12), dtype=np.int32) for _ in range(3)]
+    for mode in range(3):
+        hm.hm_lidf_dcum(ctypes.c_int(mode), ctypes.c_int64(n), dp(a), dp(b), dp(F[mode]), J[mode].ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
+    assert np.isfinite(F[0]).all()
+    assert np.max(np.abs(F[1] - F[0])) < 2e-14                 # same iterates up to rounding
+    assert np.max(np.abs(F[2] - F[1])) < 2e-14                 # the jump lands on the iterate the loop stops at
+    assert J[2][:3000].mean() > 0.8                            # ... and is what runs in the benchmark ranges
+    ref = oracle.calculate_leafangles(a[:200], b[:200])        # (n, 13) class weights of the oracle (pinned to the reference)
+    got = np.diff(np.concatenate([np.zeros((200, 1)), F[2][:200], np.ones((200, 1))], axis=1), axis=1)
+    assert np.max(np.abs(got - ref)) < 1e-13
