@@ -330,7 +330,7 @@ def main():
             ok = ok and all(bool(torch.isfinite(g).all().item()) for gl in gather_lists for g in gl)
         value = Bg * args.steps / dt
         stage_ms = {k: v / max(ncalls, 1) for k, v in stage.items()}
-        band_kernel = "k_bands<float, 0, 1, false>" if args.dtype == "float32" else "k_bands<double, 0, 1, true>"
+        band_kernel = "k_bands<float, 0, 1, true>" if args.dtype == "float32" else "k_bands<double, 0, 1, true>"
         line = {
             "metric": METRIC,
             "value": value, "unit": "spectra/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

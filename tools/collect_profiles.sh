@@ -34,4 +34,6 @@ cd $R
 timeout -k 10 120 python tools/prospect_bench.py > $O/c2_bench.txt 2>&1
 timeout -k 10 120 python tools/prospect_bench.py 1000000 float64 5 >> $O/c2_bench.txt 2>&1
 timeout -k 10 120 python tools/prospect_bench.py 1000000 float32 5 >> $O/c2_bench.txt 2>&1
+timeout -k 10 300 python tools/mode_cost.py > $O/mode_cost.txt 2>&1
+timeout -k 10 300 python tools/lut_rate.py > $O/lut_rate.txt 2>&1
 echo done > $O/DONE

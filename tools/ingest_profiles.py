@@ -126,7 +126,7 @@ if c2:
     json.dump({"src_hash": src_hash(), "batch": 10_000, "kernels": c2,
                "_note": "per launch, BASELINE config 2 (tools/prospect_bench.py 10000 float64); FETCH_SIZE / WRITE_SIZE in KB as reported"},
               open(os.path.join(dst, f"{tag}_c2_counters.json"), "w"), indent=1)
-for name in ("bench.json", "c2_bench.txt"):
+for name in ("bench.json", "c2_bench.txt", "mode_cost.txt", "lut_rate.txt"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, f"{tag}_{name}"))
 print(json.dumps(calib, indent=1))
