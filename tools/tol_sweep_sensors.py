@@ -14,7 +14,7 @@ for sensor in SENSORS:
     ref = O.spart_run(Ph[:512], sensor, T, pso="gl")
     row = {}
     for k in ("R_TOC", "R_TOA", "L_TOA"):
-        d = (o32[k].double() - o64[k]).abs() / o64[k].abs().clamp_min(1e-3)
+        d = (o32[k].double() - o64[k]).abs() / o64[k].abs().clamp_min(1e-6)
         g = o64[k][:512].cpu().numpy()
-        row[k] = "f32-f64 max %.1e | f64-oracle max %.1e" % (float(d.max()), float(np.max(np.abs(g - ref[k]) / np.maximum(np.abs(ref[k]), 1e-3))))
+        row[k] = "f32-f64 max %.1e | f64-oracle max %.1e" % (float(d.max()), float(np.max(np.abs(g - ref[k]) / np.maximum(np.abs(ref[k]), 1e-6))))
     print(sensor, e.nb, json.dumps(row), flush=True)
