@@ -33,10 +33,15 @@ struct spart_ctx {
   double* coef = nullptr;    // (48, nb)
   double* econv = nullptr;   // (nb)
   std::vector<double> econv_host;
+  // the default float32 mode runs its float64 slot pass + sensor kernel on this side stream, beside the full-band
+  // kernel (fork / join with the two events below; spart_run_batch stays asynchronous on the caller's stream)
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // optional timing of the dominant kernel (k_bands): event pairs recorded on the caller's stream
   bool profile = false;
   std::vector<hipEvent_t> ev;   // NEV events per timed call (run_impl)
   size_t ev_used = 0;
+  std::vector<char> ev_forked;  // per timed call: slot pass + sensor kernel ran on the side stream
   mutable char err[512] = {0};
 };
 
@@ -325,34 +330,23 @@ static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_
   hipLaunchKernelGGL((k_bands<T, M, F, SLOTS>), grid, dim3(TILE), 0, st, tab, cst, Bp, need, ctx->nslot,         \
                      (T*)(HYBRID ? nullptr : (void*)G), B, chunk, mp, bsum)
   const bool four = opt && opt->band_mean;     // the four band sums are only kept apart when their means are asked for
-  bool slots_done = !HYBRID;                   // (the non-hybrid band kernels write the G rows themselves)
-  if (mat && mp.rdry_in && full && four) SPART_LAUNCH_BANDS(2, 2);
-  else if (mat && mp.rdry_in && full) SPART_LAUNCH_BANDS(2, 1);
-  else if (mat && mp.rdry_in) SPART_LAUNCH_BANDS(2, 0);
-  else if (mat && full && four) SPART_LAUNCH_BANDS(1, 2);
-  else if (mat && full) SPART_LAUNCH_BANDS(1, 1);
-  else if (mat) SPART_LAUNCH_BANDS(1, 0);
-  else if (full && four) SPART_LAUNCH_BANDS(0, 2);
-  else if (full) SPART_LAUNCH_BANDS(0, 1);
-  else slots_done = false;                     // columns only, pruning allowed: evaluate just the sensor's bands
-#undef SPART_LAUNCH_BANDS
-  HIP_TRY(ctx, hipGetLastError());
-  if (prof) HIP_TRY(ctx, hipEventRecord(ev[2], st));
-  if (!slots_done) {
-    const int64_t nblk = (B + 255) / 256;                              // 256-sample blocks, dealt to the XCDs in groups of 8
-    hipLaunchKernelGGL((k_slots<TG, T>), dim3((unsigned)(((nblk + 7) / 8) * 8 * ctx->nslot)), dim3(256), 0, st, tabG,
-                       cstG, Bp, (const int*)ctx->slot_band, G, (TG*)(want_rsoil ? gs : nullptr),
-                       (const T*)(opt ? opt->rdry_in : nullptr), ctx->po, B, ctx->nslot);
-    HIP_TRY(ctx, hipGetLastError());
-  }
-  if (prof) HIP_TRY(ctx, hipEventRecord(ev[3], st));
-  if (opt && opt->band_mean) {
-    hipLaunchKernelGGL((k_bandmean<T>), dim3((4 * NWLS + 255) / 256), dim3(256), 0, st, (const T*)bsum, nchunk, B,
-                       (T*)opt->band_mean);
-    HIP_TRY(ctx, hipGetLastError());
-  }
-  SensorTab stb{ctx->slot0, ctx->slot1, ctx->frac, ctx->coef, ctx->econv, ctx->nb, ctx->nslot};
-  {
+  const bool bands = mat || full;              // the full-band kernel runs (otherwise: pruned, slot pass only)
+  const bool slots_done = !HYBRID && bands;    // (the non-hybrid band kernels write the G rows themselves)
+  // Default float32 mode: the sensor columns do not depend on the full-band kernel at all (slot pass -> sensor kernel),
+  // so those two float64 kernels run on the context's side stream BESIDE the float32 full-band kernel and fill issue
+  // slots it leaves idle; the caller's stream waits for them at the end.
+  const bool fork = HYBRID && bands && ctx->side != nullptr;
+  hipStream_t s2 = fork ? ctx->side : st;
+  auto columns = [&]() -> int {                // slot pass (where the G rows are not there yet) + sensor kernel, on s2
+    if (!slots_done) {
+      const int64_t nblk = (B + 255) / 256;                            // 256-sample blocks, dealt to the XCDs in groups of 8
+      hipLaunchKernelGGL((k_slots<TG, T>), dim3((unsigned)(((nblk + 7) / 8) * 8 * ctx->nslot)), dim3(256), 0, s2, tabG,
+                         cstG, Bp, (const int*)ctx->slot_band, G, (TG*)(want_rsoil ? gs : nullptr),
+                         (const T*)(opt ? opt->rdry_in : nullptr), ctx->po, B, ctx->nslot);
+      HIP_TRY(ctx, hipGetLastError());
+    }
+    if (prof) HIP_TRY(ctx, hipEventRecord(ev[3], s2));
+    SensorTab stb{ctx->slot0, ctx->slot1, ctx->frac, ctx->coef, ctx->econv, ctx->nb, ctx->nslot};
     const int narr = 3 + (want_rsoil ? 1 : 0) + ((opt && opt->La) ? 1 : 0);
     const size_t lds = (size_t)narr * 64 * ctx->nb * sizeof(T);      // <= 5 * 64 * 64 * 8 = 160 KiB only for nb = 64 fp64
     if (lds > 64 * 1024) return fail(ctx, SPART_ERR_INVALID, "spart_run_batch: %d sensor bands need %zu B of LDS staging", ctx->nb, lds);
@@ -361,13 +355,39 @@ static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_
     const int nwave = ctx->nb < 4 ? ctx->nb : 4;
     const GLayout gl = slots_done ? GLayout{4, 1, (int64_t)ctx->nslot * 4, 1, (int64_t)ctx->nslot}     // written by k_bands
                                   : GLayout{4 * Bp, Bp, 1, Bp, 1};                                       // written by k_slots
-    hipLaunchKernelGGL((k_sensor<T, TG>), dim3((unsigned)((B + 63) / 64)), dim3(64 * nwave), lds, st, stb, (const TG*)G, gl,
+    hipLaunchKernelGGL((k_sensor<T, TG>), dim3((unsigned)((B + 63) / 64)), dim3(64 * nwave), lds, s2, stb, (const TG*)G, gl,
                        (const double*)atm, Bp, B, (T*)R_TOC, (T*)R_TOA, (T*)L_TOA, (const TG*)(want_rsoil ? gs : nullptr),
                        (T*)(opt ? opt->rsoil : nullptr), (T*)(opt ? opt->La : nullptr));
+    HIP_TRY(ctx, hipGetLastError());
+    if (prof) HIP_TRY(ctx, hipEventRecord(ev[4], s2));
+    return SPART_OK;
+  };
+  if (fork) {                                  // side stream first: its kernels are in the queue before the 65k workgroups of k_bands
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+    if ((rc = columns())) return rc;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->side));
   }
+  if (mat && mp.rdry_in && full && four) SPART_LAUNCH_BANDS(2, 2);
+  else if (mat && mp.rdry_in && full) SPART_LAUNCH_BANDS(2, 1);
+  else if (mat && mp.rdry_in) SPART_LAUNCH_BANDS(2, 0);
+  else if (mat && full && four) SPART_LAUNCH_BANDS(1, 2);
+  else if (mat && full) SPART_LAUNCH_BANDS(1, 1);
+  else if (mat) SPART_LAUNCH_BANDS(1, 0);
+  else if (full && four) SPART_LAUNCH_BANDS(0, 2);
+  else if (full) SPART_LAUNCH_BANDS(0, 1);
+#undef SPART_LAUNCH_BANDS
   HIP_TRY(ctx, hipGetLastError());
+  if (prof) HIP_TRY(ctx, hipEventRecord(ev[2], st));
+  if (opt && opt->band_mean) {
+    hipLaunchKernelGGL((k_bandmean<T>), dim3((4 * NWLS + 255) / 256), dim3(256), 0, st, (const T*)bsum, nchunk, B,
+                       (T*)opt->band_mean);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  if (fork) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
+  else if ((rc = columns())) return rc;
   if (prof) {
-    HIP_TRY(ctx, hipEventRecord(ev[4], st));
+    ctx->ev_forked.push_back(fork ? 1 : 0);
     ctx->ev_used += NEV;
   }
   return SPART_OK;
@@ -453,6 +473,9 @@ int spart_ctx_destroy(spart_ctx* ctx) {
   (void)hipFree(ctx->slot0); (void)hipFree(ctx->slot1); (void)hipFree(ctx->frac); (void)hipFree(ctx->coef);
   (void)hipFree(ctx->econv);
   for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+  if (ctx->side) (void)hipStreamDestroy(ctx->side);
   delete ctx;
   return SPART_OK;
 }
@@ -565,6 +588,18 @@ int spart_ctx_create(spart_ctx** out, int device, const spart_tables* t) {
   if ((rc = upload(ctx, &ctx->need_slot, need)) || (rc = upload(ctx, &ctx->no_slot, std::vector<int>(NTILE * TILE, -1)))) {
     std::snprintf(g_err, 512, "%s", ctx->err); spart_ctx_destroy(ctx); return rc;
   }
+  {
+    const char* e = std::getenv("SPART_SIDE_STREAM");            // "0" keeps every kernel on the caller's stream
+    if (!(e && e[0] == '0')) {
+      if (hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess ||
+          hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
+        fail(nullptr, SPART_ERR_HIP, "spart_ctx_create: side stream / events");
+        spart_ctx_destroy(ctx);
+        return SPART_ERR_HIP;
+      }
+    }
+  }
   *out = ctx;
   return SPART_OK;
 }
@@ -574,6 +609,7 @@ int spart_profile_enable(spart_ctx* ctx, int max_calls) {
   DeviceGuard guard(ctx->device);
   ctx->profile = max_calls > 0;
   ctx->ev_used = 0;
+  ctx->ev_forked.clear();
   while (ctx->ev.size() < (size_t)(max_calls > 0 ? NEV * max_calls : 0)) {
     hipEvent_t e;
     HIP_TRY(ctx, hipEventCreate(&e));
@@ -589,15 +625,21 @@ int spart_profile_read_stages(spart_ctx* ctx, double stage_ms[SPART_NSTAGE], int
   for (int k = 0; k < SPART_NSTAGE; ++k) stage_ms[k] = 0.0;
   int n = 0;
   for (size_t i = 0; i + NEV <= ctx->ev_used; i += NEV) {
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev[i + 2]));
     HIP_TRY(ctx, hipEventSynchronize(ctx->ev[i + NEV - 1]));
+    // events: 0 before the prelude, 1 after it, 2 after the full-band kernel, 3 after the slot pass, 4 after the sensor
+    // kernel.  When 3 and 4 were recorded on the side stream the slot pass started at event 1, beside the band kernel.
+    const bool forked = n < (int)ctx->ev_forked.size() && ctx->ev_forked[n];
+    const int from[SPART_NSTAGE] = {0, 1, forked ? 1 : 2, 3}, to[SPART_NSTAGE] = {1, 2, 3, 4};
     for (int k = 0; k < SPART_NSTAGE; ++k) {
       float ms = 0.f;
-      HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[i + k], ctx->ev[i + k + 1]));
+      HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[i + from[k]], ctx->ev[i + to[k]]));
       stage_ms[k] += ms;
     }
     ++n;
   }
   ctx->ev_used = 0;
+  ctx->ev_forked.clear();
   *ncalls = n;
   return SPART_OK;
 }

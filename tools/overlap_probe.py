@@ -1,41 +1,39 @@
-"""Probe: does splitting the batch over two streams (so that the fp64 prelude / sensor kernels of one half run
-beside the band kernel of the other half) shorten a step?"""
-import os, sys, time, statistics
+"""Probe: consecutive steps issued on two alternating streams (own workspace and result buffers each), so that the
+prelude / slot pass / sensor kernel of step i+1 overlap the full-band kernel of step i -- against the same steps on one
+stream.
+
+    python tools/overlap_probe.py [B]"""
+import os
+import sys
+import time
+
 ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 sys.path.insert(0, os.path.join(ROOT, "spart-python_amd"))
-import torch
-from spart_amd import workloads
-from spart_amd.engine import Engine
-B = 1_000_000
-P = torch.as_tensor(workloads.lhs_params(B, "full").T.copy(), device="cuda:0")
-e1, e2 = Engine("Sentinel2A-MSI", 0), Engine("Sentinel2A-MSI", 0)
-res = torch.empty((3, B, 13), device="cuda:0")
-def out(lo, hi): return {"R_TOC": res[0, lo:hi], "R_TOA": res[1, lo:hi], "L_TOA": res[2, lo:hi]}
-s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
-def single():
-    e1.run(P, "float32", out=out(0, B))
-def split(nparts):
-    bounds = [B * i // nparts for i in range(nparts + 1)]
-    for i in range(nparts):
-        st, eng = (s1, e1) if i % 2 == 0 else (s2, e2)
-        with torch.cuda.stream(st):
-            lo, hi = bounds[i], bounds[i + 1]
-            eng.run(P[:, lo:hi].contiguous() if False else P[:, lo:hi], "float32", out=out(lo, hi))
-Ph = [P[:, :B // 2].contiguous(), P[:, B // 2:].contiguous()]
-def split2():
-    with torch.cuda.stream(s1):
-        e1.run(Ph[0], "float32", out=out(0, B // 2))
-    with torch.cuda.stream(s2):
-        e2.run(Ph[1], "float32", out=out(B // 2, B))
-Pq = [P[:, B * i // 4: B * (i + 1) // 4].contiguous() for i in range(4)]
-def split4():
-    for i in range(4):
-        st, eng = (s1, e1) if i % 2 == 0 else (s2, e2)
-        with torch.cuda.stream(st):
-            eng.run(Pq[i], "float32", out=out(B * i // 4, B * (i + 1) // 4))
-for name, fn in (("single", single), ("split2", split2), ("split4", split4), ("single", single), ("split2", split2)):
-    for _ in range(2): fn()
-    torch.cuda.synchronize(); ts = []
-    for _ in range(8):
-        t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
-    print(f"{name:8s} min {min(ts):.3f} med {statistics.median(ts):.3f} ms")
+import torch  # noqa: E402
+from spart_amd import get_engine, workloads  # noqa: E402
+
+for B in ([int(sys.argv[1])] if len(sys.argv) > 1 else [1_000_000, 125_000]):
+    eng = get_engine("Sentinel2A-MSI", 0)
+    P = torch.as_tensor(workloads.lhs_params(B, "full").T.copy(), device="cuda:0")
+    n = int(eng.lib.spart_workspace_bytes(eng.ctx, 0, B))
+    for nstream in (1, 2, 3):
+        streams = [torch.cuda.Stream() for _ in range(nstream)]
+        ws = [torch.empty(n, dtype=torch.uint8, device="cuda:0") for _ in range(nstream)]
+        outs = [{k: torch.empty((B, eng.nb), dtype=torch.float32, device="cuda:0") for k in ("R_TOC", "R_TOA", "L_TOA")} for _ in range(nstream)]
+        torch.cuda.synchronize()
+
+        def run(steps):
+            for i in range(steps):
+                j = i % nstream
+                with torch.cuda.stream(streams[j]):
+                    eng.run(P, "float32", out=outs[j], _workspace=ws[j])
+            torch.cuda.synchronize()
+        run(4)
+        best = 1e9
+        for _ in range(3):
+            t0 = time.perf_counter()
+            run(20)
+            best = min(best, (time.perf_counter() - t0) / 20)
+        ref = eng.run(P, "float32")
+        ok = all(torch.equal(ref[k], outs[j][k]) for j in range(nstream) for k in ref)
+        print(f"B={B} streams={nstream}: {best * 1e3:.3f} ms/step  {B / best:.3e} spectra/s  identical={ok}", flush=True)
