@@ -435,7 +435,7 @@ static int lut_impl(spart_ctx* ctx, int64_t B, int nb, const void* lut, int64_t 
   }
   HIP_TRY(ctx, hipGetLastError());
   hipLaunchKernelGGL((k_lut_reduce<T>), dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, (const T*)pc, (const int64_t*)pi,
-                     (const T*)obs, (const T*)weights, nb, M, nslice, best_idx, (T*)best_cost);
+                     (const T*)lut, (const T*)obs, (const T*)weights, nb, M, nslice, best_idx, (T*)best_cost);
   HIP_TRY(ctx, hipGetLastError());
   return SPART_OK;
 }

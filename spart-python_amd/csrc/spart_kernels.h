@@ -742,9 +742,9 @@ __global__ __launch_bounds__(256) void k_lut_scan2(const float* __restrict__ pad
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_lut_reduce(const T* __restrict__ part_cost, const int64_t* __restrict__ part_idx,
-                                                    const T* __restrict__ obs, const T* __restrict__ w, int nb, int64_t M,
-                                                    int nslice, int64_t* __restrict__ best_idx,
-                                                    T* __restrict__ best_cost) {
+                                                    const T* __restrict__ lut, const T* __restrict__ obs,
+                                                    const T* __restrict__ w, int nb, int64_t M, int nslice,
+                                                    int64_t* __restrict__ best_idx, T* __restrict__ best_cost) {
   const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= M) return;
   T best = INFINITY;
@@ -756,14 +756,20 @@ __global__ __launch_bounds__(256) void k_lut_reduce(const T* __restrict__ part_c
       bi = part_idx[(int64_t)s * M + m];
     }
   }
-  T yy = T(0);
-  for (int j = 0; j < nb; ++j) {
-    T y = obs[m * nb + j];
-    yy += (w ? w[j] : T(1)) * y * y;
+  // The scan ranks rows by n_b - 2 sum w x y (+ sum w y^2): in float32 that difference of O(|y|^2) terms carries an
+  // absolute error of ~1e-7 |y|^2, fine for ranking reflectances but not a cost to report (radiance-scale columns,
+  // exact members).  The winner's cost is therefore recomputed directly, sum_j w_j (x_j - y_j)^2, from its LUT row.
+  T c = T(0);
+  if (bi >= 0) {
+    for (int j = 0; j < nb; ++j) {
+      const T d = lut[bi * nb + j] - obs[m * nb + j];
+      c += (w ? w[j] : T(1)) * d * d;
+    }
+  } else {
+    c = INFINITY;                                // no finite row at all
   }
   best_idx[m] = bi;
-  T c = best + yy;
-  best_cost[m] = c > T(0) ? c : T(0);             // weighted sum of squared differences (rounding can leave -1e-9)
+  best_cost[m] = c;
 }
 
 }  // namespace spart
