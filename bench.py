@@ -121,7 +121,10 @@ def roofline(dtype, B, nb, stage_ms, step_ms, band_kernel):
                    "flop-eq, so this is << 1 by construction"}
     r = {"bound": "valu", "kernel": band_kernel, "kernel_ms": kern_s * 1e3, "achieved": achieved, "peak": peak,
          "unit": "TFLOP/s", "frac": achieved / peak, "flop_eq_per_spectrum": FLOP_EQ_PER_SPECTRUM,
-         "stage_ms": stage_ms, "traffic": None, "hbm": hbm}
+         "stage_ms": stage_view(stage_ms, dtype), "traffic": None, "hbm": hbm}
+    if "columns_beside_bands" in r["stage_ms"]:
+        r["note"] = ("kernel_ms is the band kernel's duration IN the timed region, where k_slots + k_sensor (float64) run beside it "
+                     "on a side stream and take some of its issue slots; stage_ms_serial = the same kernels one after the other")
     c, source, fresh = counters(dtype)
     if c is not None and B == c.get("batch") and nb == c.get("nb"):
         k = c["kernels"]
@@ -139,6 +142,38 @@ def roofline(dtype, B, nb, stage_ms, step_ms, band_kernel):
                         "counter_bytes_per_kernel": {n: v["hbm_bytes"] for n, v in k.items() if v.get("in_step")},
                         "correction": c.get("correction"), "source": source, "profiled_sources_match": fresh})
     return r
+
+
+def stage_view(stage_ms, dtype):
+    """Per-stage HIP-event times as the bench line shows them.  In the default float32 mode the float64 slot pass and the
+    sensor kernel run on the context's side stream BESIDE the full-band kernel (spart_capi.hip: fork / join), so their
+    events measure when they finished relative to the end of the prelude, not how long they would take alone: they are
+    shown as one entry, `columns_beside_bands`, and the step is prelude + max(bands, columns_beside_bands)."""
+    if dtype == "float32" and os.environ.get("SPART_SIDE_STREAM", "1") != "0":
+        return {"prelude": stage_ms["prelude"], "bands": stage_ms["bands"],
+                "columns_beside_bands": stage_ms["slots"] + stage_ms["sensor"]}
+    return dict(stage_ms)
+
+
+def serial_stages(torch, sensor, dev_index, P, dtype, steps=3):
+    """The same step with every kernel on ONE stream (SPART_SIDE_STREAM=0, a second context): the kernels' own durations."""
+    from spart_amd.engine import Engine
+    old = os.environ.get("SPART_SIDE_STREAM")
+    os.environ["SPART_SIDE_STREAM"] = "0"
+    try:
+        eng = Engine(sensor, dev_index)
+    finally:
+        if old is None:
+            del os.environ["SPART_SIDE_STREAM"]
+        else:
+            os.environ["SPART_SIDE_STREAM"] = old
+    eng.run(P, dtype)
+    eng.profile(steps)
+    for _ in range(steps):
+        eng.run(P, dtype)
+    st, n = eng.profile_read_stages()
+    eng.profile(0)
+    return {k: v / max(n, 1) for k, v in st.items()}
 
 
 def timed(torch, fn, steps, warmup):
@@ -169,7 +204,7 @@ def run_config(torch, eng, P, dtype, steps, warmup, graph=False, **kw):
     eng.profile(0)
     ok = all(bool(torch.isfinite(v).all().item()) for v in out.values())
     return {"value": B / sec, "unit": "spectra/s", "ms_per_step": sec * 1e3, "batch": B, "steps": steps,
-            "stage_ms": {k: v / max(n, 1) for k, v in st.items()}, "finite": ok, "hip_graph": bool(graph)}
+            "stage_ms": stage_view({k: v / max(n, 1) for k, v in st.items()}, dtype), "finite": ok, "hip_graph": bool(graph)}
 
 
 def extras(torch, args, dev):
@@ -352,6 +387,8 @@ def main():
             "roofline": roofline(args.dtype, B, nb, stage_ms, dt / args.steps * 1e3, band_kernel),
         }
         line["cpu_baseline"] = cpu
+        if world == 1 and "columns_beside_bands" in line["roofline"]["stage_ms"]:
+            line["roofline"]["stage_ms_serial"] = serial_stages(torch, args.sensor, dev_index, P, args.dtype)
         if world == 1 and not args.no_extras and args.dtype == "float32":
             line["fp64"], line["configs"] = extras(torch, args, dev)
         print(json.dumps(line), flush=True)
