@@ -17,7 +17,10 @@
  *     always computed in float64);
  *   - spectra and result columns are row-major (B, nbands), band-contiguous, in `dtype`; the row pitch of the
  *     2162- / 2001-wide spectrum arrays is the row width unless spart_ctx_set_row_pitch says otherwise;
- *   - `stream` is a hipStream_t (NULL = default stream); calls are asynchronous on it;
+ *   - `stream` is a hipStream_t (NULL = default stream); calls are asynchronous on it (spart_run_batch may run some
+ *     of its kernels on a side stream the context owns; it joins them back into `stream` before it returns, so the
+ *     caller sees plain stream semantics, HIP-graph capture included).  Calls on ONE context must not be issued from
+ *     several host threads at once (one context per thread otherwise);
  *   - return value 0 = ok, <0 = error (spart_last_error gives the text).  Numerical trouble
  *     propagates as NaN/inf exactly like the reference (no clamping).
  */
