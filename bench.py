@@ -144,12 +144,12 @@ def roofline(dtype, B, nb, stage_ms, step_ms, band_kernel):
     return r
 
 
-def stage_view(stage_ms, dtype):
+def stage_view(stage_ms, dtype, f32_bands=False):
     """Per-stage HIP-event times as the bench line shows them.  In the default float32 mode the float64 slot pass and the
     sensor kernel run on the context's side stream BESIDE the full-band kernel (spart_capi.hip: fork / join), so their
     events measure when they finished relative to the end of the prelude, not how long they would take alone: they are
     shown as one entry, `columns_beside_bands`, and the step is prelude + max(bands, columns_beside_bands)."""
-    if dtype == "float32" and os.environ.get("SPART_SIDE_STREAM", "1") != "0":
+    if (dtype == "float32" or f32_bands) and os.environ.get("SPART_SIDE_STREAM", "1") != "0":
         return {"prelude": stage_ms["prelude"], "bands": stage_ms["bands"],
                 "columns_beside_bands": stage_ms["slots"] + stage_ms["sensor"]}
     return dict(stage_ms)
@@ -204,7 +204,8 @@ def run_config(torch, eng, P, dtype, steps, warmup, graph=False, **kw):
     eng.profile(0)
     ok = all(bool(torch.isfinite(v).all().item()) for v in out.values())
     return {"value": B / sec, "unit": "spectra/s", "ms_per_step": sec * 1e3, "batch": B, "steps": steps,
-            "stage_ms": stage_view({k: v / max(n, 1) for k, v in st.items()}, dtype), "finite": ok, "hip_graph": bool(graph)}
+            "stage_ms": stage_view({k: v / max(n, 1) for k, v in st.items()}, dtype, bool(kw.get("f32_bands"))), "finite": ok,
+            "hip_graph": bool(graph)}
 
 
 def extras(torch, args, dev):
@@ -216,6 +217,16 @@ def extras(torch, args, dev):
     r = run_config(torch, eng, P, "float64", steps, 1)
     r["roofline"] = roofline("float64", args.batch, eng.nb, r["stage_ms"], r["ms_per_step"], "k_bands<double, 0, 1, true>")
     r["dtype"] = "f64"
+    # float64 columns over a float32 full-band pass (spart_materialize.f32_bands): the SAME float64 columns -- checked
+    # here bit for bit -- at the float32 mode's speed; the 2162 bands of every sample are still all evaluated, in float32
+    ref = {k: v.clone() for k, v in eng.run(P, "float64").items()}
+    m = run_config(torch, eng, P, "float64", steps, 1, f32_bands=True)
+    got = eng.run(P, "float64", f32_bands=True)
+    r["columns_over_f32_bands"] = {"value": m["value"], "unit": "spectra/s", "ms_per_step": m["ms_per_step"],
+                                   "bit_identical_to_fp64_mode": all(bool(torch.equal(ref[k], got[k])) for k in ref),
+                                   "what": "float64 R_TOC / R_TOA / L_TOA (prelude, sensor-slot bands, SMAC, TOC->TOA in float64); "
+                                           "the evaluation of all 2162 bands per sample (band sums) in float32"}
+    del ref, got
     fp64 = r
     cfg = {}
     # config 2: PROSPECT-5D leaf only, 10k x 2001, fp64: outputs refl, tran, kChlrel (48 096 B per leaf spectrum)

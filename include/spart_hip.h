@@ -96,6 +96,11 @@ typedef struct spart_materialize {
                                   conservative PROSPECT-PRO leaves, where the reference's canopy formulas cancel,
                                   sailh.py:185-214); materialised spectra and band_mean stay float32 arithmetic.
                                   1: the columns are taken from the float32 band arithmetic itself */
+  int32_t f32_bands;           /* dtype SPART_F64 only.  1: R_TOC / R_TOA / L_TOA (and rsoil, La) are float64 and IDENTICAL
+                                  to the float64 mode's -- prelude, sensor-slot bands, SMAC and TOC->TOA in float64 --
+                                  while the evaluation of all 2162 bands of every sample (the band sums) runs in float32:
+                                  the reference's precision on the columns at the float32 mode's speed.  Materialised
+                                  spectra, band_mean and rdry_in cannot be combined with it (SPART_ERR_INVALID). */
 } spart_materialize;
 
 int spart_ctx_create(spart_ctx **out, int device, const spart_tables *tables);

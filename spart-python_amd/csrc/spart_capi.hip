@@ -152,7 +152,7 @@ Workspace carve(int dtype, int64_t B, int nslot) {
   size_t o = 0;
   // float32 constants only in the float32 modes; the float64 constants, the G rows and the rsoil slots are sized for
   // float64 in both (the default float32 mode keeps them in float64: k_slots<double>)
-  w.cstf_off = o; o = align_up(o + (dtype == SPART_F64 ? 0 : Bp * NCONST * 4));
+  w.cstf_off = o; o = align_up(o + Bp * NCONST * 4);     // (float64 calls use it with spart_materialize.f32_bands)
   w.cstd_off = o; o = align_up(o + Bp * NCONST * 8);
   w.atm_off = o;  o = align_up(o + Bp * NATM * 8);
   w.g_off = o;    o = align_up(o + Bp * ns * 4 * 8);
@@ -259,7 +259,8 @@ static int sailh_impl(spart_ctx* ctx, int64_t B, const void* rho, const void* ta
 // T = dtype of the full-band kernel and of the outputs; TG = dtype of the prelude's constants, of the G rows at the
 // sensor slots and of the rsoil slots.  <double,double> = float64 mode; <float,double> = the default float32 mode
 // (sensor-slot bands re-evaluated in float64, k_bands_pruned); <float,float> = spart_materialize.f32_columns.
-template <typename T, typename TG>
+// TO = dtype of the (B, nb) outputs: T, except for float64 columns over a float32 full-band pass (f32_bands).
+template <typename T, typename TG, typename TO = T>
 static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_NPARAM], const double* rho_th,
                     const double* tau_th, void* R_TOC, void* R_TOA, void* L_TOA, const spart_materialize* opt, char* wsp,
                     const Workspace& ws, hipStream_t st) {
@@ -348,16 +349,16 @@ static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_
     if (prof) HIP_TRY(ctx, hipEventRecord(ev[3], s2));
     SensorTab stb{ctx->slot0, ctx->slot1, ctx->frac, ctx->coef, ctx->econv, ctx->nb, ctx->nslot};
     const int narr = 3 + (want_rsoil ? 1 : 0) + ((opt && opt->La) ? 1 : 0);
-    const size_t lds = (size_t)narr * 64 * ctx->nb * sizeof(T);      // <= 5 * 64 * 64 * 8 = 160 KiB only for nb = 64 fp64
+    const size_t lds = (size_t)narr * 64 * ctx->nb * sizeof(TO);     // <= 5 * 64 * 64 * 8 = 160 KiB only for nb = 64 fp64
     if (lds > 64 * 1024) return fail(ctx, SPART_ERR_INVALID, "spart_run_batch: %d sensor bands need %zu B of LDS staging", ctx->nb, lds);
     // 4 waves (each walking every 4th band) per 64-sample workgroup: with one wave per band (13 for Sentinel-2) a
     // CU holds a single workgroup and the kernel is 0.25 ms per 1M spectra slower (sweep 2..13: 2-4 equal)
     const int nwave = ctx->nb < 4 ? ctx->nb : 4;
     const GLayout gl = slots_done ? GLayout{4, 1, (int64_t)ctx->nslot * 4, 1, (int64_t)ctx->nslot}     // written by k_bands
                                   : GLayout{4 * Bp, Bp, 1, Bp, 1};                                       // written by k_slots
-    hipLaunchKernelGGL((k_sensor<T, TG>), dim3((unsigned)((B + 63) / 64)), dim3(64 * nwave), lds, s2, stb, (const TG*)G, gl,
-                       (const double*)atm, Bp, B, (T*)R_TOC, (T*)R_TOA, (T*)L_TOA, (const TG*)(want_rsoil ? gs : nullptr),
-                       (T*)(opt ? opt->rsoil : nullptr), (T*)(opt ? opt->La : nullptr));
+    hipLaunchKernelGGL((k_sensor<TO, TG>), dim3((unsigned)((B + 63) / 64)), dim3(64 * nwave), lds, s2, stb, (const TG*)G, gl,
+                       (const double*)atm, Bp, B, (TO*)R_TOC, (TO*)R_TOA, (TO*)L_TOA, (const TG*)(want_rsoil ? gs : nullptr),
+                       (TO*)(opt ? opt->rsoil : nullptr), (TO*)(opt ? opt->La : nullptr));
     HIP_TRY(ctx, hipGetLastError());
     if (prof) HIP_TRY(ctx, hipEventRecord(ev[4], s2));
     return SPART_OK;
@@ -751,6 +752,14 @@ int spart_run_batch(spart_ctx* ctx, int dtype, int64_t B, const double* const pa
   for (int i = 0; i < SPART_NPARAM; ++i)
     if (!params[i] && !(opt && opt->rdry_in && i >= 9 && i <= 11))   // B, lat, lon are unused with user dry spectra
       return fail(ctx, SPART_ERR_INVALID, "spart_run_batch: params[%d] is null", i);
+  if (dtype == SPART_F64 && opt && opt->f32_bands) {
+    // float64 columns (identical to the float64 mode's) over a float32 full-band pass: nothing the float32 kernel
+    // would have to write in float64 may be requested
+    if (opt->leaf_refl || opt->leaf_tran || opt->leaf_kchl || opt->soil_refl || opt->soil_refl_dry || opt->rso || opt->rdo ||
+        opt->rsd || opt->rdd || opt->band_mean || opt->rdry_in || opt->f32_columns)
+      return fail(ctx, SPART_ERR_INVALID, "spart_run_batch: f32_bands goes with the sensor columns (and rsoil / La) only");
+    return run_impl<float, double, double>(ctx, B, params, rho_thermal, tau_thermal, R_TOC, R_TOA, L_TOA, opt, wsp, ws, st);
+  }
   if (dtype == SPART_F64) return run_impl<double, double>(ctx, B, params, rho_thermal, tau_thermal, R_TOC, R_TOA, L_TOA, opt, wsp, ws, st);
   return (opt && opt->f32_columns)
              ? run_impl<float, float>(ctx, B, params, rho_thermal, tau_thermal, R_TOC, R_TOA, L_TOA, opt, wsp, ws, st)

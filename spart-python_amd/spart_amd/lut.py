@@ -41,9 +41,11 @@ def _prefault(a):
     return _libc.madvise(lo, a.ctypes.data + a.nbytes - lo, _MADV_POPULATE_WRITE) == 0
 
 
-def generate_lut(params, sensor, path=None, dtype="float32", chunk=1 << 20, device=None, prune=False, fault_threads=8):
+def generate_lut(params, sensor, path=None, dtype="float32", chunk=1 << 20, device=None, prune=False, fault_threads=8,
+                 f32_bands=False):
     """params: (B, 27) array-like on the HOST (numpy / memmap).  Returns dict of host arrays (np.memmap when
-    ``path`` is given).  ``prune=True`` evaluates only the bands the sensor needs (identical columns).
+    ``path`` is given).  ``prune=True`` evaluates only the bands the sensor needs (identical columns);
+    ``dtype="float64", f32_bands=True`` gives float64 columns identical to the float64 mode's at the float32 mode's speed.
 
     Pipeline per chunk i (three HIP streams; the host never holds a private staging copy):
         upload(i+1)   H2D of the next (n, 27) rows straight from the caller's table + on-device transpose to the
@@ -118,7 +120,7 @@ def generate_lut(params, sensor, path=None, dtype="float32", chunk=1 << 20, devi
         compute.wait_event(ev_in[j])
         res = dout[j][:, :n]
         Pd = dsoa[j] if n == chunk else dsoa[j][:, :n].contiguous()
-        eng.run(Pd, dtype, out={"R_TOC": res[0], "R_TOA": res[1], "L_TOA": res[2]}, prune=prune)
+        eng.run(Pd, dtype, out={"R_TOC": res[0], "R_TOA": res[1], "L_TOA": res[2]}, prune=prune, f32_bands=f32_bands)
         ev_done[j].record(compute)
 
     fault_threads = max(0, int(fault_threads))

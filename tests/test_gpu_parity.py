@@ -233,6 +233,23 @@ def test_float32_columns_are_the_float64_columns_rounded(golden, torch_mod):
         assert float(((b[k].double() - a[k]).abs() / a[k].abs()).max()) < 1e-6, k     # (the spectra themselves were rounded)
 
 
+def test_float64_columns_over_float32_bands(golden, torch_mod):
+    """spart_materialize.f32_bands: float64 columns bit-identical to the float64 mode's (same prelude, slot pass, SMAC),
+    with the all-band evaluation in float32; against the reference's golden rows; invalid combinations are refused."""
+    from spart_amd import get_engine
+    g = golden["e2e"]
+    for name in ("lhs_full/Sentinel2A-MSI", "lhs_pro/Sentinel2B-MSI", "lhs_small/TerraAqua-MODIS"):
+        eng = get_engine(name.split("/")[1], 0)
+        P = torch_mod.as_tensor(g[name + "/P"].T.copy(), device="cuda:0")
+        a = {k: v.clone() for k, v in eng.run(P, "float64", materialize=("rsoil", "La")).items()}
+        b = eng.run(P, "float64", f32_bands=True, materialize=("rsoil", "La"))
+        for k in ("R_TOC", "R_TOA", "L_TOA", "rsoil", "La"):
+            assert b[k].dtype == torch_mod.float64 and torch_mod.equal(a[k], b[k]), (name, k)
+            assert rel_err(b[k].cpu().numpy(), g[f"{name}/{k}"], COLFLOOR) < 1e-6, (name, k)
+    with pytest.raises(RuntimeError, match="f32_bands"):
+        eng.run(P, "float64", f32_bands=True, materialize=("rso",))
+
+
 def test_reference_style_api(golden, torch_mod, capsys):
     """import SPART; SPART.SPART(...).run() -> the reference's DataFrame (README quickstart pins)."""
     import SPART
