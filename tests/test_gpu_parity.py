@@ -76,6 +76,43 @@ def test_sailh_golden(golden, dtype, torch_mod):
         assert rel_err(o.cpu().numpy(), g[k], FLOOR[dtype]) < TOL[dtype], k
 
 
+def test_reference_test_grids_all_rows(golden, oracle, tables, torch_mod):
+    """The reference's own unit-test grids IN FULL (its tests draw 10 of these rows unless run with --all, and the parquet
+    files with the expected values are missing from the snapshot): the 6480-case PROSPECT grid
+    (tests/unit/test_PROSPECT/build_PROSPECT_tests.py:38-50) and the 8100-case SAILH grid
+    (tests/unit/test_SAILH/build_SAILH_tests.py:87-101, default leaf / soil fixtures, dso = 0 hot-spot cases and the
+    non-physical |a| + |b| > 1 LIDFs included), HIP float64 through the C ABI against the oracle, with the reference's own
+    assertion precision: assert_almost_equal (7 decimals = 1.5e-7) on the leaf spectra, assert_array_almost_equal
+    (6 decimals = 1.5e-6) on the canopy spectra -- and float32 at 1e-4 of max(|ref|, 1e-2)."""
+    import itertools
+    from spart_amd import get_engine
+    eng = get_engine(None, 0)
+    grid = np.array(list(itertools.product(range(10, 90, 10), (0.005, 0.015), (0.02, 0.06, 0.10), (0.0, 0.5, 1.0), (10, 20, 30),
+                                           (10, 20, 30), (1.0, 1.5, 2.0, 2.5, 3.0))), dtype=np.float64)
+    assert grid.shape == (6480, 7)
+    leaf = np.concatenate([grid, np.zeros((6480, 2))], axis=1)            # LeafBiology(*row): PROT = CBC = 0
+    ref = oracle.prospect_5d(leaf, tables)
+    out = eng.prospect(list(leaf.T), "float64")
+    for got, want, name in zip(out, ref, ("refl", "tran", "kChlrel")):
+        assert np.max(np.abs(got.cpu().numpy() - want)) < 1.5e-7, name
+    out32 = eng.prospect(list(leaf.T), "float32")
+    for got, want, name in zip(out32, ref, ("refl", "tran", "kChlrel")):
+        assert rel_err(got.cpu().numpy(), want, 1e-2) < 1e-4, name
+    # SAILH grid over the default leaf / soil fixtures (tests/conftest.py:48-112 of the reference = the golden file's spectra)
+    g = golden["sailh"]
+    can = np.array(list(itertools.product((1, 4, 7), (-1, -0.6, -0.2, 0.2, 0.6), (-1, -0.6, -0.2, 0.2, 0.6), (0.01, 0.06, 0.11, 0.16),
+                                          (0, 30, 60), (0, 30, 60), (0, 80, 160))), dtype=np.float64)
+    assert can.shape == (8100, 7)
+    want = oracle.sailh(g["leaf_refl"][None], g["leaf_tran"][None], g["soil_refl"][None], can[:, :4], can[:, 4:], pso="gl")
+    got = eng.sailh(g["leaf_refl"][None], g["leaf_tran"][None], g["soil_refl"][None], list(can[:, :4].T), list(can[:, 4:].T), "float64")
+    for o, k in zip(got, ("rso", "rdo", "rsd", "rdd")):
+        assert np.max(np.abs(o.cpu().numpy() - want[k])) < 1.5e-6, k
+        assert rel_err(o.cpu().numpy(), want[k], 1e-3) < 1e-6, k        # (and the north-star tolerance)
+    got32 = eng.sailh(g["leaf_refl"][None], g["leaf_tran"][None], g["soil_refl"][None], list(can[:, :4].T), list(can[:, 4:].T), "float32")
+    for o, k in zip(got32, ("rso", "rdo", "rsd", "rdd")):
+        assert rel_err(o.cpu().numpy(), want[k], 1e-2) < 1e-4, k
+
+
 @pytest.mark.parametrize("sensor", ["Sentinel2A-MSI", "Sentinel2B-MSI", "TerraAqua-MODIS", "LANDSAT7-ETM",
                                     "LANDSAT8-OLI", "Sentinel3A-OLCI"])
 def test_smac_golden(golden, sensor, torch_mod):
