@@ -127,6 +127,35 @@ def test_smac_golden(golden, sensor, torch_mod):
         assert rel_err(out[f].cpu().numpy(), g[f"{sensor}/{f}"], 1e-3) < tol, f
 
 
+def test_bsm_and_smac_random_sweeps(oracle, tables, torch_mod):
+    """The two stages the reference never tested on their own: BSM + soilwat on 4000 random soils
+    (brightness / latitude / longitude / moisture, incl. SMp <= 5 = dry branch, SMC and film varied) and SMAC on 3000
+    random geometries / atmospheres for each of the nine sensors (psi up to 360 deg for the cos(psi * 180/pi) quirk,
+    zero gas columns), HIP float64 against the oracle at the north-star tolerance; BSM also in float32."""
+    from spart_amd import get_engine, SENSORS
+    from spart_amd.engine import SMAC_FIELDS
+    rng = np.random.default_rng(2024)
+    n = 4000
+    soil = np.column_stack([rng.uniform(0.1, 1.0, n), rng.uniform(-40, 40, n), rng.uniform(60, 140, n), rng.uniform(0, 60, n),
+                            rng.uniform(10, 50, n), rng.uniform(0.005, 0.03, n)])
+    soil[:50, 3] = rng.uniform(0, 5, 50)                                  # mu <= 0: rwet = rdry (bsm.py:101-103)
+    ref = oracle.bsm(soil, tables)
+    eng = get_engine(None, 0)
+    for dtype in ("float64", "float32"):
+        out = eng.bsm(list(soil.T), dtype)
+        for got, want, name in zip(out, ref, ("refl", "refl_dry")):
+            assert rel_err(got.cpu().numpy(), want, FLOOR[dtype]) < TOL[dtype], (dtype, name)
+    m = 3000
+    ang = np.column_stack([rng.uniform(0, 75, m), rng.uniform(0, 60, m), rng.uniform(0, 360, m)])
+    atm = np.column_stack([rng.uniform(0.0, 0.8, m), rng.uniform(0.0, 0.5, m), rng.uniform(0.0, 5.0, m), rng.uniform(600, 1050, m)])
+    atm[:20, 1:3] = 0.0
+    for sensor in SENSORS:
+        want = oracle.smac(ang, atm, oracle.sensor_tables(tables, sensor))
+        got = get_engine(sensor, 0).smac(list(ang.T), list(atm.T))
+        for f in SMAC_FIELDS:
+            assert rel_err(got[f].cpu().numpy(), want[f], 1e-3) < 1e-9, (sensor, f)
+
+
 def _e2e_groups(golden):
     g = golden["e2e"]
     return sorted(set(k.rsplit("/", 1)[0] for k in g.files))
