@@ -231,15 +231,27 @@ template <> struct Mx<double> {
   static SPART_HD double exp2(double x) { return ::exp2(x); }
   static SPART_HD double log(double x) { return ::log(x); }
 #endif
-  static SPART_HD double sqrt(double x) { return ::sqrt(x); }
-  // reciprocal: v_rcp_f64 refined by two Newton steps (~1 ulp for normal arguments, 5 instructions) instead of
-  // the ~12-instruction IEEE division sequence; the host build divides
+  // square root: v_rsq_f64 (4.6e-8 relative) refined by ONE third-order step, sqrt x = g (1 + e/2 + 3 e^2/8 + O(e^3)),
+  // g = x y0, e = 1 - g y0: 6 instructions + a class test for 0 / inf, against ~14 of the library's sequence
+  static SPART_HD double sqrt(double x) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(SPART_FAST_MATH)
+    const double y0 = __builtin_amdgcn_rsq(x);
+    const double g = x * y0;
+    const double e = __builtin_fma(-g, y0, 1.0);
+    const double s = __builtin_fma(g, e * __builtin_fma(0.375, e, 0.5), g);
+    return __builtin_amdgcn_class(x, 0x260) ? x : s;        // +-0 and +inf pass through; negative -> NaN (v_rsq)
+#else
+    return ::sqrt(x);
+#endif
+  }
+  // reciprocal: v_rcp_f64 (4.6e-8 relative, tools/ubench/rcp64_probe) refined by ONE second-order step,
+  // 1/x = r (1 + e + e^2 + O(e^3)), e = 1 - x r: 4 instructions and the last bit (two Newton steps: 5; the IEEE division
+  // sequence: ~12); the host build divides
   static SPART_HD double rcp(double x) {
 #if defined(__HIP_DEVICE_COMPILE__) && defined(SPART_FAST_MATH)
-    double r = __builtin_amdgcn_rcp(x);
-    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
-    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
-    return r;
+    const double r = __builtin_amdgcn_rcp(x);
+    const double e = __builtin_fma(-x, r, 1.0);
+    return __builtin_fma(__builtin_fma(e, e, e), r, r);
 #else
     return 1.0 / x;
 #endif
