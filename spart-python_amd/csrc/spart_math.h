@@ -358,6 +358,7 @@ template <typename T> SPART_HD T sail_j2_d(T L, T tk, T e1, T kpm, T ikpm) {
 template <typename T> struct E3c;
 template <> struct E3c<float> {
   static constexpr int GD = E3_G_DEG_F32, WD = E3_W_DEG_F32;
+  static constexpr float PSCALE = 2.0f;      // pt() holds P; the factor 2 is folded into the literals by the compiler
   static SPART_HD const float* gt() { return E3_G_F32; }     // (instruction literals after unrolling)
   static SPART_HD const float* pt() { return E3_P_F32; }
   static SPART_HD const float* qt() { return E3_Q_F32; }
@@ -373,11 +374,17 @@ static_assert(E3_G_DEG_F64 == 12 && E3_W_DEG_F64 == 6, "tables below list the co
 #define SPART_L13(a) {a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], a[10], a[11], a[12]}
 #define SPART_L7(a) {a[0], a[1], a[2], a[3], a[4], a[5], a[6]}
 __device__ __constant__ double c_E3_G_F64[13] = SPART_L13(E3_G_F64);
-__device__ __constant__ double c_E3_P_F64[7] = SPART_L7(E3_P_F64);
+#define SPART_L7X2(a) {2 * a[0], 2 * a[1], 2 * a[2], 2 * a[3], 2 * a[4], 2 * a[5], 2 * a[6]}
+__device__ __constant__ double c_E3_P_F64[7] = SPART_L7X2(E3_P_F64);   // 2 P: the factor 2 of tau = 2 E3 folded in (exact)
 __device__ __constant__ double c_E3_Q_F64[7] = SPART_L7(E3_Q_F64);
 #endif
 template <> struct E3c<double> {
   static constexpr int GD = E3_G_DEG_F64, WD = E3_W_DEG_F64;
+#if defined(__HIP_DEVICE_COMPILE__)
+  static constexpr double PSCALE = 1.0;      // the device table already holds 2 P (seven multiplications per band saved)
+#else
+  static constexpr double PSCALE = 2.0;
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
   static SPART_HD spart_cdp gt() { return spart_fresh(c_E3_G_F64); }
   static SPART_HD spart_cdp pt() { return spart_fresh(c_E3_P_F64); }
@@ -414,10 +421,10 @@ template <typename T> SPART_HD void plate_tau(T K, T& tau, T& u) {
     // P(t)/Q(t) with t = 1/x, written in x (coefficients reversed) so that a single reciprocal is needed:
     // tau = e^-x * 2 Pr(x) / ((x + 3) Qr(x)),  Pr(x) = x^n P(1/x)
     const auto cp = C::pt(), cq = C::qt();
-    T pn = T(2) * cp[0], qn = cq[0];       // (the factor 2 is folded into P's constants: exact)
+    T pn = C::PSCALE * cp[0], qn = cq[0];  // (the factor 2 is folded into P's constants: exact)
 #pragma unroll
     for (int i = 1; i <= C::WD; ++i) {
-      pn = horner_step(pn, x, T(2) * cp[i]);
+      pn = horner_step(pn, x, C::PSCALE * cp[i]);
       qn = horner_step(qn, x, cq[i]);
     }
     v = Mx<T>::exp(-x) * pn * Mx<T>::rcp((x + T(3)) * qn);
