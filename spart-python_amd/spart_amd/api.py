@@ -113,8 +113,8 @@ class SoilParameters:
 
 
 class SoilParametersFromFile:
-    """bsm.py:155-226 with the dry spectrum passed as an array ((2001,), (2001,1) or (B,2001)).
-    Parsing JPL spectral-library text files is host-side I/O outside the hot path."""
+    """bsm.py:155-226: the dry spectrum as an array ((2001,), (2001,1) or (B,2001)) or the path of a JPL / ASTER
+    spectral-library text file (host-side parsing; the spectrum then enters the path like any user rdry)."""
 
     def __init__(self, soil_file, SMp, SMC=None, film=None):
         if SMC is None:
@@ -128,11 +128,59 @@ class SoilParametersFromFile:
             self.film = 0.0150
         else:
             self.film = film
-        if not isinstance(soil_file, np.ndarray):
-            raise NotImplementedError("pass the dry soil reflectance as a numpy array (400-2400 nm, 1 nm)")
-        self.rdry = soil_file
+        if isinstance(soil_file, np.ndarray):
+            self.rdry = soil_file
+        else:
+            self.rdry = self._load_jpl_soil_refl(soil_file)
         self.SMp = SMp
         self.rdry_set = True
+
+    @staticmethod
+    def _load_jpl_soil_refl(file_path):
+        """bsm.py:201-226, same result on the same file, NaNs included.  The file: 21 header lines, then
+        `wavelength [um] <tab> reflectance [% or fraction]`, wavelengths DESCENDING (the reference slices labels 2401..400
+        in file order; an ascending file gives it an empty slice and an all-NaN spectrum, reproduced here with a warning).
+        Steps of the reference kept as they are: percent is detected on the whole file (any value > 1); wavelengths
+        become nm by a float64 `* 1000`, so a file wavelength counts as "on the 1 nm grid" only if that product is the
+        integer exactly; grid wavelengths the file lacks are filled by pandas' `interpolate("linear")`, which is linear
+        in ROW POSITION, not in wavelength (np.interp over positions, as pandas does), leaves leading gaps NaN and fills
+        trailing gaps with the last value."""
+        rows = []
+        with open(file_path) as f:
+            for i, line in enumerate(f):
+                if i < 21 or not line.strip():
+                    continue
+                a = line.rstrip("\n").split("\t")
+                rows.append((float(a[0]), float(a[1]) if len(a) > 1 and a[1].strip() else np.nan))
+        if not rows:
+            raise ValueError(f"no spectrum rows after the 21 header lines of {file_path}")
+        t = np.asarray(rows, dtype=np.float64)
+        wl, v = t[:, 0] * 1000, t[:, 1]
+        if np.any(v > 1):
+            v = v / 100
+        dec, inc = bool(np.all(np.diff(wl) <= 0)), bool(np.all(np.diff(wl) >= 0))
+        if dec:
+            keep = (wl <= 2401) & (wl >= 400)
+        elif inc:
+            warnings.warn(f"{file_path}: wavelengths ascend; the reference's loader expects descending order and returns NaN")
+            keep = np.zeros(len(wl), dtype=bool)
+        else:
+            raise KeyError(f"{file_path}: wavelengths are not monotonic")
+        wl, v = wl[keep], v[keep]
+        grid = np.arange(400, 2401, 1).astype(np.float64)
+        missing = grid[~np.isin(grid, wl)]
+        wl = np.concatenate([wl, missing])
+        v = np.concatenate([v, np.full(len(missing), np.nan)])
+        o = np.argsort(wl, kind="stable")
+        wl, v = wl[o], v[o]
+        ok = ~np.isnan(v)
+        if ok.any():
+            pos = np.arange(len(v), dtype=np.float64)
+            filled = np.interp(pos, pos[ok], v[ok])
+            filled[: int(np.argmax(ok))] = np.nan
+            v = filled
+        at = np.searchsorted(wl, grid)
+        return v[at][:, None]
 
     def columns(self):
         return [None, None, None, self.SMp, self.SMC, self.film]

@@ -15,6 +15,9 @@ Files
   smac.npz       per sensor: angles, atm + the 9 AtmosphericOptics fields (smac.py:14)
   e2e.npz        full SPART(...).run() rows: defaults x 9 sensors, README/MODIS, PRO/S2B,
                  256 rows of the config-4 LHS (S2A), 64 rows config-5 LHS (S2B), 32 LHS rows MODIS/L7/S3A
+  jpl.npz        SoilParametersFromFile(<path>).rdry (2001,1) for the synthetic JPL-format text files of jpl/
+                 (written by this script: descending percent with irregular steps, fraction units, a file that
+                 starts above 400 nm, an ascending file) (bsm.py:201-226)
   edge.npz       128 rows of tools/edge_sweep.py's widened ranges with edge values (LAI 0 / 1e-4 / 10, dry soil, N = 1,
                  zero pigments, exact hot spot, grazing angles, PRO leaves), Sentinel2A: P + R_TOC / R_TOA / L_TOA
 """
@@ -227,6 +230,72 @@ def gen_rdry():
     print("rdry", len(rows))
 
 
+def write_jpl_files():
+    """Synthetic spectra in the layout of the JPL / ASTER soil files the reference parses (bsm.py:203-206: 21 header lines,
+    then `wavelength [um] <tab> reflectance`), data of this repository's own making."""
+    d = os.path.join(HERE, "jpl")
+    os.makedirs(d, exist_ok=True)
+    rng = np.random.default_rng(11)
+
+    def grid(lo_um, hi_um):
+        # 2 nm steps to 0.8 um, then 4 nm, then 10 nm, with a few off-grid points (x.5 nm) as real files have
+        w = np.concatenate([np.arange(400, 800, 2), np.arange(800, 2500, 4), np.arange(2500, 14000, 10)]).astype(np.float64)
+        w[5::37] += 0.5
+        w = w[(w >= lo_um * 1000) & (w <= hi_um * 1000)]
+        return w / 1000.0
+
+    def refl(w_um):
+        x = w_um * 1000
+        return 0.12 + 0.22 * (1 - np.exp(-(x - 400) / 600.0)) - 0.07 * np.exp(-((x - 1900) / 70.0) ** 2) - 0.05 * np.exp(-((x - 1400) / 50.0) ** 2)
+
+    def write(name, w, r, unit):
+        head = ["Name: synthetic soil %s" % name, "Type: Soil", "Class: Synthetic", "Subclass: none", "Particle Size: Fine",
+                "Sample No.: 0", "Owner: spart-python_amd tests", "Wavelength Range: All", "Origin: generated",
+                "Collection Date: N/A", "Description: synthetic spectrum in the JPL text layout", "Geologic age: none",
+                "Measurement: Directional (10 Degree) Hemispherical Reflectance", "First Column: X", "Second Column: Y",
+                "X Units: Wavelength (micrometers)", "Y Units: Reflectance (%s)" % unit, "First X Value: %g" % w[0],
+                "Last X Value: %g" % w[-1], "Number of X Values: %d" % len(w), "Additional Information: none"]
+        assert len(head) == 21
+        with open(os.path.join(d, name + ".txt"), "w") as f:
+            f.write("\n".join(head) + "\n")
+            for a, b in zip(w, r):
+                f.write("%.4f\t%.4f\n" % (a, b))
+
+    w = grid(0.4, 14.0)[::-1]
+    write("descending_percent", w, 100 * refl(w) + rng.normal(0, 0.05, len(w)), "percent")
+    write("descending_fraction", w, refl(w), "fraction")
+    w2 = grid(0.42, 3.0)[::-1]
+    write("starts_at_420nm", w2, 100 * refl(w2), "percent")
+    write("ascending_percent", w[::-1], 100 * refl(w[::-1]), "percent")
+    return d, ["descending_percent", "descending_fraction", "starts_at_420nm", "ascending_percent"]
+
+
+def gen_jpl():
+    """SoilParametersFromFile with a file path (bsm.py:201-226) on the synthetic files of jpl/."""
+    import warnings
+    from SPART.bsm import SoilParametersFromFile
+    d, names = write_jpl_files()
+    out = {}
+    warnings.filterwarnings("ignore")
+    for n in names:
+        try:
+            out[n] = np.asarray(SoilParametersFromFile(os.path.join(d, n + ".txt"), 20, 25, 0.015).rdry, dtype=np.float64)
+            print(n, out[n].shape, "NaN:", int(np.isnan(out[n]).sum()), out[n][[0, 1, 2, 1000, 2000], 0])
+        except Exception as e:                                   # the reference's behaviour on this file IS the fixture
+            out[n + "/error"] = np.array(type(e).__name__)
+            print(n, "raises", type(e).__name__, e)
+    # the full chain on the first file (SPART.py:192-199 with rdry_set), defaults of tests/conftest.py
+    dflt = workloads.default_row()[0]
+    with redirect_stdout(io.StringIO()):
+        sp = SPART.SPART(SoilParametersFromFile(os.path.join(d, names[0] + ".txt"), 20, 25, 0.015), LeafBiology(*dflt[0:7]),
+                         CanopyStructure(*dflt[15:19]), AtmosphericProperties(dflt[22], dflt[23], dflt[24], Pa=dflt[25]),
+                         Angles(*dflt[19:22]), "Sentinel2A-MSI", 100)
+        df = sp.run(debug=True)
+    for c in ("R_TOC", "R_TOA", "L_TOA", "rsoil"):
+        out["run/" + c] = df[c].to_numpy()
+    np.savez_compressed(os.path.join(HERE, "jpl.npz"), **out)
+
+
 def gen_edge():
     import warnings
     import edge_sweep                      # tools/edge_sweep.py: the generator of the widened-range rows
@@ -242,6 +311,6 @@ def gen_edge():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["prospect", "bsm", "sailh", "smac", "e2e", "rdry", "edge"]
+    which = sys.argv[1:] or ["prospect", "bsm", "sailh", "smac", "e2e", "rdry", "jpl", "edge"]
     for w in which:
         globals()["gen_" + w]()

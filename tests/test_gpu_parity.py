@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import rel_err
+from conftest import ROOT, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -369,6 +369,21 @@ def test_reference_style_api(golden, torch_mod, capsys):
     assert rad.rso.shape == (2162, 1)
     assert abs(rad.rso[400, 0] - 0.40396347479496547) < 1e-6 and abs(rad.rdd[2100, 0] - 0.005657296144770152) < 1e-6
     assert abs(canopy.lidf[0, 0] - 0.037891833294514) < 1e-12
+
+
+def test_soil_parameters_from_a_jpl_file_through_the_chain(golden):
+    """SPART.SPART(SoilParametersFromFile(<path>), ...).run(debug=True) (bsm.py:155-226, 42-43; SPART.py:192-199) against
+    the reference's run on the same synthetic JPL-layout file (tests/golden/jpl/, make_golden.py jpl)."""
+    import SPART
+    g = golden["jpl"]
+    d = np.load(os.path.join(ROOT, "tests", "golden", "e2e.npz"))["defaults/Sentinel2A-MSI/P"][0]
+    soil = SPART.SoilParametersFromFile(os.path.join(ROOT, "tests", "golden", "jpl", "descending_percent.txt"), 20, 25, 0.015)
+    df = SPART.SPART(soil, SPART.LeafBiology(*d[0:7]), SPART.CanopyStructure(*d[15:19]),
+                     SPART.AtmosphericProperties(d[22], d[23], d[24], Pa=d[25]), SPART.Angles(*d[19:22]), "Sentinel2A-MSI", 100).run(debug=True)
+    for c in ("R_TOC", "R_TOA", "L_TOA", "rsoil"):
+        assert rel_err(df[c].to_numpy(), g["run/" + c], COLFLOOR) < 1e-6, c
+    so = SPART.BSM(soil)
+    assert so.refl_dry.shape == (2001, 1) and np.array_equal(so.refl_dry, g["descending_percent"])
 
 
 def test_all_bands_are_evaluated_and_prune_is_equivalent(oracle, tables, torch_mod):

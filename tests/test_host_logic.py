@@ -118,8 +118,8 @@ def test_batch_result_long_dataframe():
 def test_engine_input_validation_messages():
     """Host-side checks that run before any GPU work."""
     import SPART
-    with pytest.raises(NotImplementedError):
-        SPART.SoilParametersFromFile("some_file.txt", 20, 25, 0.015)      # JPL text parsing is out of scope
+    with pytest.raises(FileNotFoundError):
+        SPART.SoilParametersFromFile("some_file.txt", 20, 25, 0.015)
     s = SPART.SoilParametersFromFile(np.zeros((2001, 1)), 20, 25, 0.015)
     assert s.rdry_set is True and s.columns()[:3] == [None, None, None]
 
@@ -172,3 +172,21 @@ def test_lut_parquet_export(golden, tmp_path):
     assert list(df.columns[:27]) == workloads.PARAM_NAMES and df.shape == (256, 27 + 3 * 13)
     assert np.array_equal(df[[f"R_TOC_{w:g}" for w in wl]].to_numpy(), g[name + "/R_TOC"])
     assert np.array_equal(df[f"L_TOA_{wl[0]:g}"].to_numpy(), g[name + "/L_TOA"][:, 0]) and df["Cab"].iloc[3] == g[name + "/P"][3, 0]
+
+
+def test_jpl_soil_file_loader_matches_the_reference(golden):
+    """SoilParametersFromFile(<path>) (bsm.py:201-226) on the synthetic JPL-layout files of tests/golden/jpl/: the
+    reference's own loader produced tests/golden/jpl.npz (make_golden.py jpl).  Bit for bit, NaNs in the same places:
+    position-linear gap filling, float `um * 1000` grid matching, leading gaps NaN, ascending file all NaN."""
+    import os
+    import SPART
+    from conftest import ROOT
+    g = golden["jpl"]
+    for name in ("descending_percent", "descending_fraction", "starts_at_420nm", "ascending_percent"):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            s = SPART.SoilParametersFromFile(os.path.join(ROOT, "tests", "golden", "jpl", name + ".txt"), 20, 25, 0.015)
+        assert s.rdry_set and s.rdry.shape == (2001, 1) and s.rdry.dtype == np.float64
+        assert np.array_equal(s.rdry, g[name], equal_nan=True), name
+    assert np.isnan(g["starts_at_420nm"][:20]).all() and not np.isnan(g["starts_at_420nm"][20:]).any()
+    assert np.isnan(g["ascending_percent"]).all() and not np.isnan(g["descending_percent"]).any()
