@@ -118,6 +118,12 @@ int spart_ctx_econv(const spart_ctx *ctx, double *host_out); /* (nb,) SRF-convol
  * multiple of 64 elements (2176 / 2048) 5.9 TB/s (tools/ubench/write_pattern.hip).  No reference counterpart. */
 int spart_ctx_set_row_pitch(spart_ctx *ctx, int64_t pitch_full, int64_t pitch_optical);
 
+/* calculate_tav (prospect_5d.py:249-311): average transmissivity of a dielectric plane surface for the cone half-angle
+ * alpha_deg and n refractive indices.  HOST function on host pointers, float64, no context and no GPU: it is the routine
+ * the library derives its interface tables from in spart_ctx_create, exported so that the
+ * Python mirror of the reference function runs the same arithmetic. */
+int spart_calculate_tav(double alpha_deg, const double *nr, int64_t n, double *out);
+
 /* Bytes of scratch the batched entry points need for B samples (prelude constants + the
  * canopy values at the sensor bands).  The same buffer may be reused by successive calls
  * on one stream.  spart_smac_batch sizes its workspace with dtype = SPART_F64. */

@@ -17,7 +17,7 @@ def _alias(name, names):
     return m
 
 
-bsm = _alias("bsm", ["BSM", "SoilOptics", "SoilParameters", "SoilParametersFromFile"])
-prospect_5d = _alias("prospect_5d", ["PROSPECT_5D", "LeafBiology", "LeafOptics"])
+bsm = _alias("bsm", ["BSM", "soilwat", "SoilOptics", "SoilParameters", "SoilParametersFromFile"])
+prospect_5d = _alias("prospect_5d", ["PROSPECT_5D", "LeafBiology", "LeafOptics", "calculate_tav"])
 sailh = _alias("sailh", ["SAILH", "CanopyStructure", "Angles", "CanopyReflectances", "calculate_leafangles"])
 smac = _alias("smac", ["SMAC", "AtmosphericProperties", "AtmosphericOptics", "_calculate_pressure_from_altitude"])

@@ -653,6 +653,12 @@ int spart_profile_read(spart_ctx* ctx, double* total_ms, int* ncalls) {
   return rc;
 }
 
+int spart_calculate_tav(double alpha_deg, const double* nr, int64_t n, double* out) {
+  if (!nr || !out || n < 0) { std::snprintf(g_err, 512, "spart_calculate_tav: null pointer or negative length"); return SPART_ERR_INVALID; }
+  for (int64_t i = 0; i < n; ++i) out[i] = calculate_tav(alpha_deg, nr[i]);
+  return SPART_OK;
+}
+
 size_t spart_workspace_bytes(const spart_ctx* ctx, int dtype, int64_t B) {
   if (!ctx || B <= 0) return 0;
   return carve(dtype, B, ctx->nslot).total;

@@ -455,7 +455,8 @@ inline double calculate_tav(double alpha, double nr) {
   double tp4 = 16 * n2 * n2 * (n2 * n2 + 1) * std::log((2 * n_p * b - nm * nm) / (2 * n_p * a - nm * nm)) /
                (n_p * n_p * n_p * nm * nm);
   double tp5 = 16 * n2 * n2 * n2 * (1 / (2 * n_p * b - nm * nm) - 1 / (2 * n_p * a - nm * nm)) / (n_p * n_p * n_p);
-  return (ts + tp1 + tp2 + tp3 + tp4 + tp5) / (2 * sa * sa);
+  double tp = tp1 + tp2 + tp3 + tp4 + tp5;
+  return (ts + tp) / (2 * sa * sa);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -5,7 +5,7 @@ Public names mirror wirrell/SPART-python's ``SPART`` package (src/SPART/__init__
 from .api import (BSM, PROSPECT_5D, SAILH, SMAC, SPART, Angles, AtmosphericOptics, AtmosphericProperties,  # noqa: F401
                   BatchResult, CanopyReflectances, CanopyStructure, LeafBiology, LeafOptics, SoilOptics,
                   SoilParameters, SoilParametersFromFile, SpectralBands, calculate_ET_radiance,
-                  calculate_leafangles, calculate_spectral_convolution, load_ET_parameters,
+                  calculate_leafangles, calculate_spectral_convolution, calculate_tav, soilwat, load_ET_parameters,
                   load_optical_parameters, load_sensor_info, set_leaf_refl_trans_assumptions,
                   set_soil_refl_trans_assumptions)
 from .engine import Engine, get_engine  # noqa: F401

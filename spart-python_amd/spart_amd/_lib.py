@@ -34,6 +34,7 @@ SIGNATURES = {
     "spart_ctx_nb": (ctypes.c_int, [vp]),
     "spart_ctx_econv": (ctypes.c_int, [vp, c_dp]),
     "spart_ctx_set_row_pitch": (ctypes.c_int, [vp, ctypes.c_int64, ctypes.c_int64]),
+    "spart_calculate_tav": (ctypes.c_int, [ctypes.c_double, c_dp, ctypes.c_int64, c_dp]),
     "spart_workspace_bytes": (ctypes.c_size_t, [vp, ctypes.c_int, ctypes.c_int64]),
     "spart_prospect_batch": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int64, ctypes.POINTER(vp), vp, vp, vp, vp,
                                             ctypes.c_size_t, vp]),

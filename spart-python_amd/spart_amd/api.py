@@ -69,6 +69,22 @@ def _pro_warning(leafbio):
         print(_PRO_WARNING)          # prospect_5d.py:148-155 (once per call, not per sample)
 
 
+def calculate_tav(alpha, nr):
+    """prospect_5d.py:249-311, float64 on the host through the library's own routine (spart_calculate_tav: the one the
+    context derives its interface tables from); ``nr`` scalar or array, result of the same shape."""
+    import ctypes
+    from . import _lib
+    shape = np.shape(nr)
+    a = np.ascontiguousarray(np.asarray(nr, dtype=np.float64).reshape(-1))
+    out = np.empty_like(a)
+    dp = ctypes.POINTER(ctypes.c_double)
+    lib = _lib.load()
+    rc = lib.spart_calculate_tav(float(alpha), a.ctypes.data_as(dp), a.size, out.ctypes.data_as(dp))
+    if rc != 0:
+        raise RuntimeError(lib.spart_last_error(None).decode())
+    return float(out[0]) if shape == () else out.reshape(shape)
+
+
 def PROSPECT_5D(leafbio, optical_params=None, dtype="float64", device=None):
     """prospect_5d.py:117-246.  ``optical_params`` is accepted for signature compatibility; the
     engine holds its own device copy of the same tables."""
@@ -184,6 +200,19 @@ class SoilParametersFromFile:
 
     def columns(self):
         return [None, None, None, self.SMp, self.SMC, self.film]
+
+
+def soilwat(rdry, nw, kw, SMp, SMC, deleff, dtype="float64", device=None):
+    """bsm.py:62-128: wet soil reflectance from a dry spectrum.  The water tables live in the device context
+    (model_parameters/optical_params): ``nw`` / ``kw`` must be those tables (they are checked, not used), anything else
+    is a ValueError rather than a silently different answer.  Returns the shape of ``rdry``."""
+    op = _tables.load_optical_parameters()
+    for given, name in ((nw, "nw"), (kw, "Kw")):
+        if given is not None and not np.array_equal(np.asarray(given, dtype=np.float64).reshape(-1), op[name].reshape(-1)):
+            raise ValueError(f"soilwat: {name} differs from the water table of the device context (load_optical_parameters())")
+    eng = _engine.get_engine(None, device)
+    refl, _ = eng.bsm([None, None, None, SMp, SMC, deleff], dtype, rdry=rdry)
+    return refl.cpu().numpy().reshape(np.shape(rdry)) if np.size(rdry) == 2001 else refl.cpu().numpy()
 
 
 def BSM(soilpar, optical_params=None, dtype="float64", device=None):

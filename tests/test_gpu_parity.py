@@ -386,6 +386,22 @@ def test_soil_parameters_from_a_jpl_file_through_the_chain(golden):
     assert so.refl_dry.shape == (2001, 1) and np.array_equal(so.refl_dry, g["descending_percent"])
 
 
+def test_soilwat_entry_point(oracle, tables, golden):
+    """SPART.bsm.soilwat(rdry, nw, kw, SMp, SMC, deleff) (bsm.py:62-128) with the context's water tables: against the
+    oracle's BSM on the same dry spectrum (wet branch and the mu <= 0 branch), and a foreign table is refused."""
+    import SPART
+    from SPART.bsm import soilwat
+    op = SPART.load_optical_parameters()
+    rdry = golden["rdry"]["spectra"][0][:, None]
+    for smp in (30.0, 4.0):
+        a = soilwat(rdry, op["nw"], op["Kw"], smp, 25, 0.015)
+        b, _ = oracle.bsm(np.array([[0.5, 0, 100, smp, 25, 0.015]]), tables, rdry=rdry[:, 0][None, :])
+        assert a.shape == (2001, 1) and rel_err(a[:, 0], b[0], 1e-6) < 1e-9, smp
+    assert np.array_equal(soilwat(rdry, op["nw"], op["Kw"], 4.0, 25, 0.015), rdry)         # bsm.py:101-103
+    with pytest.raises(ValueError, match="water table"):
+        soilwat(rdry, op["nw"] * 1.01, op["Kw"], 30.0, 25, 0.015)
+
+
 def test_all_bands_are_evaluated_and_prune_is_equivalent(oracle, tables, torch_mod):
     """Default mode: every band of every sample feeds the per-chunk band sums -> batch-mean canopy spectra
     must equal the oracle's means over all 2162 bands.  prune=True must give bit-identical columns."""

@@ -190,3 +190,17 @@ def test_jpl_soil_file_loader_matches_the_reference(golden):
         assert np.array_equal(s.rdry, g[name], equal_nan=True), name
     assert np.isnan(g["starts_at_420nm"][:20]).all() and not np.isnan(g["starts_at_420nm"][20:]).any()
     assert np.isnan(g["ascending_percent"]).all() and not np.isnan(g["descending_percent"]).any()
+
+
+def test_calculate_tav_host_entry_point(oracle, tables):
+    """SPART.prospect_5d.calculate_tav (prospect_5d.py:249-311) runs the library's own host routine
+    (spart_calculate_tav, no GPU): against the oracle on the refractive-index tables the path uses and on a scan."""
+    import SPART
+    from SPART.prospect_5d import calculate_tav
+    for nr in (np.asarray(tables["nr"]).reshape(-1), np.asarray(tables["nw"]).reshape(-1), 2.0 / np.asarray(tables["nw"]).reshape(-1),
+               np.linspace(1.1, 2.5, 1000)):
+        for alpha in (40, 90, 59.0):
+            a, b = calculate_tav(alpha, nr), oracle.calculate_tav(alpha, nr)
+            assert a.shape == nr.shape and np.max(np.abs(a / b - 1)) < 1e-12, alpha
+    assert isinstance(SPART.calculate_tav(90, 2.0), float) and abs(SPART.calculate_tav(90, 2.0) / oracle.calculate_tav(90, 2.0) - 1) < 1e-13
+    assert calculate_tav(40, np.full((3, 2), 1.4)).shape == (3, 2)
