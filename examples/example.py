@@ -1,0 +1,29 @@
+"""The reference's quick start (one parameter set -> the reference's DataFrame), then the same call with arrays:
+a whole look-up table in one launch.  Needs an MI355X (there is no CPU path).
+
+    python examples/example.py
+"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "spart-python_amd"))
+import SPART  # noqa: E402
+
+leafbio = SPART.LeafBiology(Cab=40, Cca=10, Cw=0.02, Cdm=0.01, Cs=0, Cant=10, N=1.5)
+soilpar = SPART.SoilParameters(B=0.5, lat=0, lon=100, SMp=20, SMC=25, film=0.015)
+canopy = SPART.CanopyStructure(LAI=3, LIDFa=-0.35, LIDFb=-0.15, q=0.05)
+angles = SPART.Angles(sol_angle=40, obs_angle=0, rel_angle=0)
+atm = SPART.AtmosphericProperties(aot550=0.325, uo3=0.35, uh2o=1.41, Pa=1013.25)
+
+# scalars in -> pandas DataFrame with Band, L_TOA, R_TOA, R_TOC, indexed by the band centres
+print(SPART.SPART(soilpar, leafbio, canopy, atm, angles, sensor="Sentinel2A-MSI", DOY=100).run())
+
+# any field may be an array of length B: 100 000 canopies, LAI and chlorophyll varying
+B = 100_000
+rng = np.random.default_rng(0)
+leafbio = SPART.LeafBiology(Cab=rng.uniform(10, 80, B), Cca=10, Cw=0.02, Cdm=0.01, Cs=0, Cant=10, N=1.5)
+canopy = SPART.CanopyStructure(LAI=rng.uniform(0.1, 7, B), LIDFa=-0.35, LIDFb=-0.15, q=0.05)
+res = SPART.SPART(soilpar, leafbio, canopy, atm, angles, sensor="Sentinel2A-MSI", DOY=100, dtype="float32").run()
+print(type(res).__name__, res["R_TOC"].shape, res["R_TOA"].mean(axis=0))

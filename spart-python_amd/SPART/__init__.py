@@ -17,6 +17,12 @@ def _alias(name, names):
     return m
 
 
+# `from SPART.SPART import SpectralBands` (tests/benchmarks/test_benchmarks.py:7): the module of that name stays
+# importable although, as in the reference (src/SPART/__init__.py:1), the ATTRIBUTE SPART.SPART is the class
+_alias("SPART", ["SPART", "SpectralBands", "calculate_ET_radiance", "calculate_spectral_convolution", "load_optical_parameters",
+                 "load_ET_parameters", "load_sensor_info", "set_soil_refl_trans_assumptions", "set_leaf_refl_trans_assumptions"])
+
+
 bsm = _alias("bsm", ["BSM", "soilwat", "SoilOptics", "SoilParameters", "SoilParametersFromFile"])
 prospect_5d = _alias("prospect_5d", ["PROSPECT_5D", "LeafBiology", "LeafOptics", "calculate_tav"])
 sailh = _alias("sailh", ["SAILH", "CanopyStructure", "Angles", "CanopyReflectances", "calculate_leafangles"])

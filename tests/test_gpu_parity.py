@@ -386,6 +386,63 @@ def test_soil_parameters_from_a_jpl_file_through_the_chain(golden):
     assert so.refl_dry.shape == (2001, 1) and np.array_equal(so.refl_dry, g["descending_percent"])
 
 
+def test_reference_example_and_benchmark_harness(golden):
+    """The reference's example script (example/example.py:7-31: every constructor by KEYWORD, SMC / film defaulted) and
+    its benchmark fixtures (tests/benchmarks/test_benchmarks.py:27-55: spectra padded by hand through
+    SpectralBands().IwlP / IwlT, imported from SPART.SPART) run unchanged against this package."""
+    import warnings
+    import SPART
+    from SPART.SPART import SpectralBands
+    from SPART.bsm import BSM, SoilParameters
+    from SPART.prospect_5d import PROSPECT_5D, LeafBiology
+    from SPART.sailh import SAILH, Angles, CanopyStructure
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        soilpar = SPART.SoilParameters(B=0.5, lat=0, lon=100, SMp=20)
+    assert len(w) == 2                                              # bsm.py:274-286: SMC, film
+    leafbio = SPART.LeafBiology(Cab=40, Cca=10, Cw=0.02, Cdm=0.01, Cs=0, Cant=10, N=1.5)
+    canopy = SPART.CanopyStructure(LAI=3, LIDFa=-0.35, LIDFb=-0.15, q=0.05)
+    angles = SPART.Angles(sol_angle=40, obs_angle=0, rel_angle=0)
+    atm = SPART.AtmosphericProperties(aot550=0.325, uo3=0.35, uh2o=1.41, Pa=1013.25)
+    df = SPART.SPART(soilpar, leafbio, canopy, atm, angles, sensor="Sentinel2A-MSI", DOY=100).run()
+    g = golden["e2e"]
+    for c in ("R_TOC", "R_TOA", "L_TOA"):
+        assert rel_err(df[c].to_numpy(), g[f"defaults/Sentinel2A-MSI/{c}"][0], COLFLOOR) < 1e-6, c
+    assert (df[["R_TOC", "R_TOA", "L_TOA"]].to_numpy() > 0).all()    # tests/e2e/test_SPART.py:40-42
+    # benchmark fixtures
+    op, sb = SPART.load_optical_parameters(), SpectralBands()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        soilopt = BSM(SoilParameters(0.5, 0, 100, 20), op)
+    rs = np.zeros((sb.nwlP + sb.nwlT, 1))
+    rs[sb.IwlP] = soilopt.refl
+    rs[sb.IwlT] = 1 * rs[sb.nwlP - 1]
+    soilopt.refl = rs
+    lb = LeafBiology(40, 0.01, 0.02, 0, 10, 10, 1.5)
+    leafopt = PROSPECT_5D(lb, op)
+    rho, tau = np.zeros((sb.nwlP + sb.nwlT, 1)), np.zeros((sb.nwlP + sb.nwlT, 1))
+    rho[sb.IwlT], tau[sb.IwlT] = lb.rho_thermal, lb.tau_thermal
+    rho[sb.IwlP], tau[sb.IwlP] = leafopt.refl, leafopt.tran
+    leafopt.refl, leafopt.tran = rho, tau
+    rad = SAILH(soilopt, leafopt, CanopyStructure(3, -0.35, -0.15, 0.05), Angles(40, 0, 0))
+    assert rad.rso.shape == (2162, 1)
+    assert abs(rad.rso[400, 0] - 0.40396347479496547) < 1e-6 and abs(rad.rdo[2100, 0] - 0.006083228593590332) < 1e-6
+
+
+def test_example_scripts_run(tmp_path):
+    """examples/example.py (quick start, scalar then batched) and examples/lut.py (LUT to disk + inversion) as a user
+    runs them: own processes, exit code 0, the expected last lines."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "example.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "R_TOC" in r.stdout and "BatchResult (100000, 13)" in r.stdout
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "lut.py"), "20000", str(tmp_path / "lut")],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "20000 rows" in r.stdout and "recovered the generating row" in r.stdout
+
+
 def test_soilwat_entry_point(oracle, tables, golden):
     """SPART.bsm.soilwat(rdry, nw, kw, SMp, SMC, deleff) (bsm.py:62-128) with the context's water tables: against the
     oracle's BSM on the same dry spectrum (wet branch and the mu <= 0 branch), and a foreign table is refused."""
