@@ -92,6 +92,11 @@ class Engine:
             self._ws_buf = self.torch.empty(max(n, 256), dtype=self.torch.uint8, device=self.device)
         return ctypes.c_void_p(self._ws_buf.data_ptr()), ctypes.c_size_t(self._ws_buf.numel())
 
+    def release_workspace(self):
+        """Drop the scratch buffer the engine keeps between calls (it grows to the largest batch seen: ~1.7 KB per
+        sample); the next call allocates what it needs."""
+        self._ws_buf = None
+
     def to_f64(self, x, B=None):
         """scalar / sequence / numpy / tensor -> contiguous float64 device tensor of length B."""
         torch = self.torch

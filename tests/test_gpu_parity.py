@@ -212,6 +212,42 @@ def test_ragged_and_edge_batches(oracle, tables, torch_mod):
     assert out["R_TOC"].shape == (0, 13)
 
 
+def test_maximum_batch_size(torch_mod):
+    """The largest batch one call takes (60 000 000 spectra: the 32-bit lane offset of the constant staging,
+    spart_capi.hip SPART_MAX_BATCH; ~100 GB of workspace, 13 GB of parameters, 9 GB of columns on the 288 GB card):
+    every entry finite, and rows from the front, the middle and the far end of the batch equal -- bit for bit -- the
+    same rows evaluated on their own (samples are independent; a wrapped offset anywhere would show here).  One more
+    sample is refused with the library's message."""
+    from spart_amd import get_engine, workloads
+    torch = torch_mod
+    eng = get_engine("Sentinel2A-MSI", 0)
+    B = 60_000_000
+    g = torch.Generator(device="cuda:0").manual_seed(5)
+    P = torch.empty((27, B), dtype=torch.float64, device="cuda:0")
+    d = workloads.default_row()[0]
+    for j, name in enumerate(workloads.PARAM_NAMES):
+        if name in workloads.RANGES and name not in ("PROT", "CBC"):
+            lo, hi = workloads.RANGES[name]
+            P[j].uniform_(lo, hi, generator=g)
+        else:
+            P[j].fill_(workloads.FIXED.get(name, d[j]))
+    out = {k: torch.empty((B, 13), dtype=torch.float32, device="cuda:0") for k in ("R_TOC", "R_TOA", "L_TOA")}
+    eng.run(P, "float32", out=dict(out))
+    torch.cuda.synchronize()
+    for k in out:
+        assert bool(torch.isfinite(out[k]).all()), k
+    for lo in (0, 7_325 * 4_000 - 100, B // 2 + 33, B - 777):       # incl. a chunk boundary of the band kernel and the tail
+        sub = eng.run(P[:, lo:lo + 777].contiguous(), "float32")
+        for k in out:
+            assert torch.equal(sub[k], out[k][lo:lo + 777]), (k, lo)
+    assert float(out["R_TOC"].double().mean()) > 0.01
+    with pytest.raises(RuntimeError, match="at most 60000000 samples"):
+        eng.run(torch.empty((27, B + 1), dtype=torch.float64, device="cuda:0"), "float32")
+    del P, out, sub
+    eng.release_workspace()
+    torch.cuda.empty_cache()
+
+
 def test_full_size_properties(torch_mod):
     """BASELINE size (1M spectra, config-4 workload): size-independent checks.
     (1) every fp32 column entry against the fp64 evaluation of the SAME 1M rows (fp64 itself is pinned to
