@@ -107,6 +107,10 @@ void hm_lidf_dcum(int mode, int64_t n, const double* a, const double* b, double*
     }
 }
 
+void hm_log1p(int dtype, int64_t n, const double* x, double* out) {
+  for (int64_t i = 0; i < n; ++i) out[i] = dtype == 0 ? (double)Mx<float>::log1p((float)x[i]) : Mx<double>::log1p(x[i]);
+}
+
 void hm_plate_tau(int dtype, int64_t n, const double* K, double* tau, double* u) {
   for (int64_t i = 0; i < n; ++i) {
     if (dtype == 0) { float t, uu; plate_tau<float>((float)K[i], t, uu); tau[i] = t; u[i] = uu; }

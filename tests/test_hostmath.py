@@ -75,6 +75,19 @@ def test_plate_transmittance(hm):
         assert np.max(np.abs(u[2:] - ref_u) / ref_u) < (1e-7 if dtype == 1 else tol)   # (the fp64 reference form itself cancels ~1e-8)
 
 
+def test_log1p_forms(hm):
+    """ln(1 + x), x >= 0, as the band arithmetic evaluates it (atanh series below 0.5 / 0.1, logarithm of 1 + x above):
+    relative accuracy over 18 decades, exact zero, huge arguments."""
+    x = np.concatenate([[0.0], np.logspace(-12, 6, 20000), [1e30]])
+    for dtype, tol in ((0, 4.0 * 2.0 ** -24), (1, 2.5e-15)):
+        xx = x.astype(np.float32).astype(np.float64) if dtype == 0 else x
+        out = np.zeros_like(xx)
+        hm.hm_log1p(ctypes.c_int(dtype), ctypes.c_int64(xx.size), dp(xx), dp(out))
+        ref = np.log1p(xx)
+        assert out[0] == 0.0
+        assert np.max(np.abs(out[1:] - ref[1:]) / ref[1:]) < tol, dtype
+
+
 @pytest.mark.parametrize("dtype,tol_spec,tol_col", [(1, 1e-8, 1e-6), (0, 1e-4, 1e-4)])
 def test_chain_vs_oracle_and_reference(hm, tab, oracle, tables, golden, dtype, tol_spec, tol_col):
     g = golden["e2e"]
