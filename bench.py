@@ -24,7 +24,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "spart-python_amd"))
 
-PROFILE_TAG = "r2"        # profiles/<tag>_counters_<dtype>.json: the committed rocprofv3 PMC passes (tools/ingest_profiles.py)
+PROFILE_TAGS = ("r3", "r2")   # profiles/<tag>_counters_<what>.json: the committed rocprofv3 PMC passes (tools/ingest_profiles.py), newest first
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_TFLOPS = {"float32": 157.3, "float64": 78.6}   # MI355X_MICROARCH.md: peak FP32 / FP64 vector
 ISSUE_CYCLES = {"float32": 2.0, "float64": 4.0}          # cycles per wave64 VALU instruction on a SIMD-32 (fp64: half rate)
@@ -54,12 +54,14 @@ def counters(dtype):
     """The committed rocprofv3 PMC passes of this build (FETCH_SIZE, WRITE_SIZE and SQ counters need separate passes
     under the profiler, so they cannot be collected inside this run): per-kernel averages per launch at B = 1M.
     -> (dict or None, source string, whether the kernel sources are the ones that were profiled)"""
-    name = f"{PROFILE_TAG}_counters_{dtype}.json"
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", name)))
-    except Exception:
-        return None, None, False
-    return d, "profiles/" + name, d.get("src_hash") == src_hash()
+    for tag in PROFILE_TAGS:
+        name = f"{tag}_counters_{dtype}.json"
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except Exception:
+            continue
+        return d, "profiles/" + name, d.get("src_hash") == src_hash()
+    return None, None, False
 
 
 def _cpu_worker(job):
@@ -262,7 +264,123 @@ def extras(torch, args, dev):
     c5["fp32_vs_fp64_max_rel_floor1e-6"] = {k: float(((a[k].double() - b[k]).abs() / b[k].abs().clamp_min(1e-6)).max().item())
                                             for k in ("R_TOC", "R_TOA", "L_TOA")}
     cfg["5"] = c5
+    del Pp, a, b
+    torch.cuda.empty_cache()
+    cfg.update(mode_records(torch, args, dev))
     return fp64, cfg
+
+
+MAT_FIELDS = ("leaf_refl", "leaf_tran", "leaf_kchl", "soil_refl", "soil_refl_dry", "rso", "rdo", "rsd", "rdd")
+MAT_BYTES_F32 = (7 * 2162 + 2 * 2001) * 4          # +75 256 B per spectrum, float32
+LUT_BOUND = "valu"                                 # k_lut_scan2: packed fp32 FMAs with the LUT rows wave-uniform
+
+
+def mode_records(torch, args, dev):
+    """Driver-timed records of the modes SURVEY.md section 8(f) adds to the path (N = 1 only): materialised spectra (the
+    one HBM-bound mode, and the one in which the full-band evaluation is CONSUMED), the pruned step (= what the returned
+    columns cost), LUT generation end to end (host table in, host columns out) and LUT inversion."""
+    import numpy as np
+    import spart_amd
+    from spart_amd import get_engine, workloads
+    rec = {}
+    eng = get_engine(args.sensor, dev.index)
+    P1m = workloads.lhs_params(1_000_000, "full")
+    # --- materialised: 9 spectrum arrays, B = 200k, float32, padded row pitch (Engine default)
+    B = 200_000
+    P = torch.as_tensor(P1m[:B].T.copy(), device=dev)
+    out = eng.run(P, "float32", materialize=MAT_FIELDS)             # allocates the nine (B, pitch) arrays once
+    mat_step = lambda: eng.run(P, "float32", materialize=MAT_FIELDS, out=out)    # noqa: E731  (caller-owned buffers)
+    steps = 10
+    sec = timed(torch, mat_step, steps, 2)
+    eng.profile(steps)
+    for _ in range(steps):
+        mat_step()
+    st, n = eng.profile_read_stages()
+    eng.profile(0)
+    kms = st["bands"] / max(n, 1)
+    nbytes = MAT_BYTES_F32 * B
+    c, source, fresh = counters("materialized")
+    traffic = None
+    if c is not None and c.get("batch") == B:
+        bk = next((v for nme, v in c["kernels"].items() if nme.replace(" ", "").startswith("k_bands<float,1,")), None)
+        traffic = bk.get("hbm_bytes") if bk else None
+    rec["materialized"] = {
+        "workload": f"full SPART + the nine leaf / soil / canopy spectrum arrays (SPART.py:66-81) written to HBM, {B} spectra of the "
+                    f"config-4 LHS, {args.sensor}, fp32, rows padded to 2176 / 2048 elements",
+        "value": B / sec, "unit": "spectra/s", "ms_per_step": sec * 1e3, "batch": B, "steps": steps,
+        "bytes_per_spectrum": MAT_BYTES_F32 + algorithmic_bytes(eng.nb, "float32"),
+        "step_GBps": (nbytes + algorithmic_bytes(eng.nb, "float32") * B) / sec / 1e9,
+        "finite": all(bool(torch.isfinite(out[k]).all().item()) for k in MAT_FIELDS),
+        "roofline": {"bound": "hbm", "kernel": "k_bands<float, 1, 1, true>", "kernel_ms": kms,
+                     "achieved": nbytes / (kms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": nbytes / (kms / 1e3) / 1e9 / HBM_PEAK_GBS, "frac_over_step": nbytes / sec / 1e9 / HBM_PEAK_GBS,
+                     "algorithmic_bytes_per_launch": nbytes, "traffic": traffic,
+                     "traffic_source": source if traffic else None, "profiled_sources_match": fresh if traffic else None,
+                     "note": "achieved = bytes of spectra stored / the band kernel's HIP-event duration (the kernel also does "
+                             "the whole 2162-band arithmetic, 2.3 ms of VALU work at this batch)"}}
+    del out, P
+    torch.cuda.empty_cache()
+    # --- pruned: only the <= 2 nb bands the sensor columns depend on; bit-identical columns.  This IS the cost of
+    # the returned R_TOC / R_TOA / L_TOA: in the headline mode they come from prelude + k_slots + k_sensor as well,
+    # the full-band kernel beside them evaluates the other bands of every spectrum (band sums, materialised spectra)
+    Pd = torch.as_tensor(P1m.T.copy(), device=dev)
+    r = run_config(torch, eng, Pd, "float32", 20, 3, prune=True)
+    full = eng.run(Pd, "float32")
+    full = {k: v.clone() for k, v in full.items()}
+    pr = eng.run(Pd, "float32", prune=True)
+    r["columns_bit_identical_to_full_evaluation"] = all(bool(torch.equal(full[k], pr[k])) for k in full)
+    r["workload"] = (f"prune_unused_bands = 1: prelude + float64 sensor-slot pass ({eng.nb} of 2162 bands) + SMAC / TOC->TOA, 1M spectra, "
+                     f"{args.sensor}; NOT full spectra -- reported as the cost of the returned columns, never as the headline")
+    rec["pruned"] = r
+    del full, pr
+    # --- LUT inversion: 1M-row LUT (this run's R_TOC columns) x 65 536 observations, float32
+    lut = eng.run(Pd, "float32")["R_TOC"].clone()
+    M = 65536
+    g = torch.Generator(device=dev).manual_seed(3)
+    pick = torch.randint(0, lut.shape[0], (M,), generator=g, device=dev)
+    obs = lut[pick] * (1 + 0.02 * torch.randn((M, lut.shape[1]), generator=g, device=dev))
+    eng0 = get_engine(None, dev.index)
+    idx, cost = eng0.lut_nearest(lut, obs)
+    sec = timed(torch, lambda: eng0.lut_nearest(lut, obs), 5, 1)
+    # brute-force check of 64 observations (float64 distances on the GPU via torch: plumbing, not the product)
+    d = ((lut.double()[None, :, :] - obs[:64].double()[:, None, :]) ** 2).sum(-1)
+    bf_cost, bf = d.min(1)
+    got_cost = ((lut[idx[:64]].double() - obs[:64].double()) ** 2).sum(-1)
+    nbp = 16 if lut.shape[1] <= 15 else 32
+    cmp_s = lut.shape[0] * M / sec
+    rec["lut_invert"] = {
+        "workload": f"spart_lut_nearest: {lut.shape[0]}-row LUT (R_TOC of the config-4 table, {lut.shape[1]} bands) x {M} noisy observations, fp32",
+        "value": cmp_s, "unit": "row comparisons/s", "ms_per_step": sec * 1e3, "steps": 5,
+        "observations_per_s": M / sec,
+        "winners_within_1e-6_of_brute_force": int(((got_cost - bf_cost).abs() <= 1e-6 * bf_cost.abs() + 1e-12).sum().item()), "checked": 64,
+        "roofline": {"bound": LUT_BOUND, "achieved": cmp_s * 2 * nbp / 1e12,
+                     "peak": VALU_PEAK_TFLOPS["float32"], "unit": "TFLOP/s", "frac": cmp_s * 2 * nbp / 1e12 / VALU_PEAK_TFLOPS["float32"],
+                     "flops_per_comparison": 2 * nbp,
+                     "note": f"2 x {nbp} flops per comparison (rows padded to {nbp} values incl. the norm slot); peak = fp32 vector / "
+                             "exact-f32 MFMA peak, both 157.3 TF (MI355X_MICROARCH.md); whole call timed (prep + scan + reduce)"}}
+    del lut, obs, idx, cost, d, pick
+    torch.cuda.empty_cache()
+    # --- LUT generation end to end: host parameter table in, host columns out (PCIe-inclusive; never the headline)
+    P8 = np.tile(P1m, (8, 1))
+    spart_amd.generate_lut(P8[:1 << 20], args.sensor, chunk=1 << 20)
+    best, bestp = 1e9, 1e9
+    for _ in range(2):
+        t0 = time.perf_counter()
+        o = spart_amd.generate_lut(P8, args.sensor, chunk=1 << 20)
+        best = min(best, time.perf_counter() - t0)
+        del o
+        t0 = time.perf_counter()
+        o = spart_amd.generate_lut(P8, args.sensor, chunk=1 << 20, prune=True)
+        bestp = min(bestp, time.perf_counter() - t0)
+        del o
+    rec["lut_generate"] = {
+        "workload": f"spart_amd.generate_lut: {P8.shape[0]} spectra (the 1M config-4 table x 8), {args.sensor}, fp32, pageable host table in -> "
+                    "host columns out, chunks of 1M, copies overlapped with the kernels; best of 2",
+        "value": P8.shape[0] / best, "unit": "spectra/s", "ms_per_step": best * 1e3,
+        "host_bytes_per_spectrum": 27 * 8 + 3 * eng.nb * 4, "host_GBps": (27 * 8 + 3 * eng.nb * 4) * P8.shape[0] / best / 1e9,
+        "pruned_value": P8.shape[0] / bestp, "pruned_ms": bestp * 1e3,
+        "note": "PCIe-inclusive, reported beside the resident-input headline (never as `value` of the line)"}
+    return rec
 
 
 def main():
@@ -311,6 +429,8 @@ def main():
     scaling = args.scaling if args.scaling != "auto" else "strong"
     eng = get_engine(args.sensor, dev_index)
     nb = eng.nb
+    from spart_amd import _lib as _spart_lib
+    build_id = _spart_lib.build_id()                  # == the hash of the sources next to the library (_lib.load checks)
     # synthetic inputs, resident in HBM before timing starts.  strong: this rank's contiguous shard of ONE global LHS
     # table (spart_amd.sharding.shard_bounds); weak: every rank its own table (seed + rank)
     if scaling == "strong":
@@ -391,7 +511,7 @@ def main():
                        "parallelism": (f"dp{world}: {'one 1M LHS table cut into contiguous shards' if scaling == 'strong' else 'one table per rank'}"
                                        " + one RCCL gather of the (3, B/N, nb) block to rank 0 per step, overlapped with the next "
                                        "step's kernels") if world > 1 else "single GPU",
-                       "input_dtype": "f64",
+                       "input_dtype": "f64", "build_id": build_id,
                        "columns": ("float32 full-band pass + float64 re-evaluation of the sensor-slot bands: columns = the float64 "
                                    "mode's, rounded once") if args.dtype == "float32" else "float64 throughout",
                        "tables": "17 table values per band held in VGPRs (lane = band); the per-sample constants, not the tables, "

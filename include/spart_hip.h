@@ -107,6 +107,11 @@ int spart_ctx_create(spart_ctx **out, int device, const spart_tables *tables);
 int spart_ctx_destroy(spart_ctx *ctx);
 const char *spart_last_error(const spart_ctx *ctx); /* ctx may be NULL: last creation error */
 
+/* Identity of this binary: 12 hex digits over the kernel / ABI sources, compiler flags and math variant it was built
+ * from (spart-python_amd/build.py: source_id).  The Python loader refuses a library whose id is not that of the
+ * sources next to it, and bench.py prints it, so a stale .so cannot be measured silently.  No reference counterpart. */
+const char *spart_build_id(void);
+
 int spart_ctx_nb(const spart_ctx *ctx);                    /* sensor bands of the context */
 int spart_ctx_econv(const spart_ctx *ctx, double *host_out); /* (nb,) SRF-convolved ET irradiance (SPART.py:389-394), copied to HOST */
 

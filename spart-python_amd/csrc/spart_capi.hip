@@ -441,7 +441,15 @@ static int lut_impl(spart_ctx* ctx, int64_t B, int nb, const void* lut, int64_t 
   return SPART_OK;
 }
 
+#ifndef SPART_BUILD_ID
+#define SPART_BUILD_ID "unidentified"      // built outside spart-python_amd/build.py
+#endif
+// tag + id: build.py finds the id in the file's bytes (binary_id), spart_build_id() returns the part after the tag
+static const char k_build_id[] = "SPART_BUILD_ID:" SPART_BUILD_ID;
+
 extern "C" {
+
+const char* spart_build_id(void) { return k_build_id + 15; }
 
 const char* spart_last_error(const spart_ctx* ctx) { return ctx ? ctx->err : g_err; }
 

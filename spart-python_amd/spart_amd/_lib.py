@@ -31,6 +31,7 @@ SIGNATURES = {
     "spart_ctx_create": (ctypes.c_int, [ctypes.POINTER(vp), ctypes.c_int, ctypes.POINTER(SpartTables)]),
     "spart_ctx_destroy": (ctypes.c_int, [vp]),
     "spart_last_error": (ctypes.c_char_p, [vp]),
+    "spart_build_id": (ctypes.c_char_p, []),
     "spart_ctx_nb": (ctypes.c_int, [vp]),
     "spart_ctx_econv": (ctypes.c_int, [vp, c_dp]),
     "spart_ctx_set_row_pitch": (ctypes.c_int, [vp, ctypes.c_int64, ctypes.c_int64]),
@@ -59,25 +60,48 @@ STAGES = ("prelude", "bands", "slots", "sensor")        # spart_profile_read_sta
 _libs = {}
 
 
+def _build_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_spart_build", os.path.join(HERE, "..", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    return b
+
+
+def expected_build_id():
+    """id of the sources next to this package (build.py: source_id) -- what the in-tree library must report"""
+    return _build_module().source_id(os.environ.get("SPART_FAST_MATH", "1") == "1")
+
+
+def build_id(lib=None):
+    """spart_build_id() of the loaded library"""
+    return (lib or load()).spart_build_id().decode()
+
+
 def load(path=None):
     """dlopen the library (torch is imported first so that its HIP runtime, soname
     libamdhip64.so.7, is the one both sides use).  ``path`` selects another build of the same
-    ABI (tools/ab_bench.py compares kernel variants in one process)."""
+    ABI (tools/ab_bench.py compares kernel variants in one process).  The in-tree library must have been built from
+    the sources next to it (content hash embedded at build time): a stale one is rebuilt when hipcc is there, and
+    refused otherwise -- never loaded silently."""
     path = os.path.abspath(path or os.environ.get("SPART_HIP_LIB") or LIB_PATH)
     if path in _libs:
         return _libs[path]
     import torch  # noqa: F401
 
-    if not os.path.exists(path) and path == os.path.abspath(LIB_PATH):
-        try:        # the .so is a build artefact (git-ignored): compile it on first use when hipcc is around
-            import importlib.util
-            spec = importlib.util.spec_from_file_location("_spart_build", os.path.join(HERE, "..", "build.py"))
-            b = importlib.util.module_from_spec(spec)
-            spec.loader.exec_module(b)
-            b.build(verbose=True)
-        except Exception as e:      # noqa: BLE001
-            raise RuntimeError(f"{path} is missing and could not be built ({e}); run `python spart-python_amd/build.py` "
-                               "(hipcc, gfx950). spart_amd has no CPU fallback.") from e
+    in_tree = path == os.path.abspath(LIB_PATH)
+    if in_tree:
+        b = _build_module()
+        want, have = expected_build_id(), b.binary_id(path)
+        if have != want:
+            try:    # the .so is a build artefact (git-ignored): compile it when it is missing or stale and hipcc is around
+                b.build(verbose=True)
+            except Exception as e:      # noqa: BLE001
+                if os.path.exists(path):
+                    raise RuntimeError(f"{path} was built from other sources (build id {have}, sources {want}) and could "
+                                       f"not be rebuilt ({e}); run `python spart-python_amd/build.py`") from e
+                raise RuntimeError(f"{path} is missing and could not be built ({e}); run `python spart-python_amd/build.py` "
+                                   "(hipcc, gfx950). spart_amd has no CPU fallback.") from e
     if not os.path.exists(path):
         raise RuntimeError(
             f"{path} is missing: build it with `python spart-python_amd/build.py` "
@@ -87,6 +111,8 @@ def load(path=None):
         fn = getattr(lib, name)  # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args
+    if in_tree and lib.spart_build_id().decode() != want:      # (what the loaded code says, not what the file's bytes said)
+        raise RuntimeError(f"{path} reports build id {lib.spart_build_id().decode()}, the sources next to it are {want}")
     _libs[path] = lib
     return lib
 

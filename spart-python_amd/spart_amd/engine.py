@@ -226,7 +226,8 @@ class Engine:
         params : (27, B) float64 device tensor (rows = spart_amd.workloads.PARAM_NAMES) or a list of 27
                  scalars / arrays.
         materialize : iterable of names from MATERIALIZE_FIELDS to also return (full spectra etc.)
-        out : optional dict with preallocated 'R_TOC','R_TOA','L_TOA' (B,nb) tensors
+        out : optional dict with preallocated 'R_TOC','R_TOA','L_TOA' (B,nb) tensors and / or preallocated tensors for
+              names in ``materialize`` (spectrum arrays on this engine's row pitch, e.g. a previous call's results)
         prune : False (default) evaluates all 2162 bands of every sample; True lets the kernel skip bands
                 that no requested output needs (identical columns, much less work)
         rdry : optional (B, 2001) / (2001,) user dry-soil spectra replacing the GSV mixing (bsm.py:42-43);
@@ -275,7 +276,14 @@ class Engine:
             for name in materialize:
                 if name not in MATERIALIZE_FIELDS:
                     raise ValueError(f"unknown materialize field {name}")
-                if name in _MAT_WIDTH:
+                if name in res:                     # caller-owned buffer (out=): must already have this context's layout
+                    shape = (B, _MAT_WIDTH[name]) if name in _MAT_WIDTH else ((4, _lib.NWLS) if name == "band_mean" else (B, self.nb))
+                    pitch = self.row_pitch[_MAT_WIDTH[name]] if name in _MAT_WIDTH else shape[1]
+                    t = res[name]
+                    if not torch.is_tensor(t) or tuple(t.shape) != shape or t.dtype != td or t.device != self.device \
+                            or (B > 1 and t.stride() != (pitch, 1)) or t.stride(-1) != 1:
+                        raise ValueError(f"out[{name!r}] must be a {shape} {td} tensor with row stride {pitch} on {self.device}")
+                elif name in _MAT_WIDTH:
                     res[name] = self._alloc_spec(B, _MAT_WIDTH[name], td)
                 else:
                     res[name] = torch.empty((4, _lib.NWLS) if name == "band_mean" else (B, self.nb), dtype=td,

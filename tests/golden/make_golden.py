@@ -18,6 +18,8 @@ Files
   jpl.npz        SoilParametersFromFile(<path>).rdry (2001,1) for the synthetic JPL-format text files of jpl/
                  (written by this script: descending percent with irregular steps, fraction units, a file that
                  starts above 400 nm, an ascending file) (bsm.py:201-226)
+  grids.npz      the reference's full unit-test grids (6480 PROSPECT + 8100 SAILH cases): 16 probe bands + the all-band mean of
+                 every spectrum (python tests/golden/make_golden.py grids; ~5 min on 8 processes)
   edge.npz       128 rows of tools/edge_sweep.py's widened ranges with edge values (LAI 0 / 1e-4 / 10, dry soil, N = 1,
                  zero pigments, exact hot spot, grazing angles, PRO leaves), Sentinel2A: P + R_TOC / R_TOA / L_TOA
 """
@@ -308,6 +310,55 @@ def gen_edge():
         out[k] = np.array([r[j] for r in res])
     np.savez_compressed(os.path.join(HERE, "edge.npz"), **out)
     print("edge", P.shape, "non-finite reference entries:", int((~np.isfinite(out["R_TOC"])).sum()))
+
+
+GRID_PROBES_LEAF = [0, 50, 100, 150, 200, 250, 280, 300, 350, 400, 570, 800, 1050, 1250, 1540, 2000]    # 400 ... 2400 nm
+GRID_PROBES_CANOPY = [0, 50, 150, 250, 280, 300, 350, 400, 570, 800, 1050, 1250, 1540, 2000, 2001, 2161]  # + first / last thermal band
+
+
+def _grid_leaf_row(r):
+    with redirect_stdout(io.StringIO()):
+        lo = PROSPECT_5D(LeafBiology(*r), _GRID_STATE["op"])
+    sp = [lo.refl[:, 0], lo.tran[:, 0], lo.kChlrel[:, 0]]
+    return np.array([s[GRID_PROBES_LEAF] for s in sp]), np.array([s.mean() for s in sp])
+
+
+def _grid_canopy_row(r):
+    lo, so = _GRID_STATE["optics"]
+    rad = SAILH(so, lo, CanopyStructure(*r[:4]), Angles(*r[4:7]))
+    sp = [getattr(rad, k)[:, 0] for k in ("rso", "rdo", "rsd", "rdd")]
+    return np.array([s[GRID_PROBES_CANOPY] for s in sp]), np.array([s.mean() for s in sp])
+
+
+_GRID_STATE = {}
+
+
+def _grid_init():
+    _GRID_STATE["op"] = SPART.load_optical_parameters()
+    _GRID_STATE["optics"] = default_optics()
+
+
+def gen_grids():
+    """The reference's own unit-test grids IN FULL, run through the reference itself: all 6480 PROSPECT cases
+    (build_PROSPECT_tests.py:38-50) and all 8100 SAILH cases (build_SAILH_tests.py:87-101, default leaf / soil fixtures).
+    The reference's parquet files with the expected values are missing from the snapshot (.MISSING_LARGE_BLOBS); whole
+    spectra would be 0.9 GB, so each spectrum is stored as 16 probe bands + its mean over ALL bands (the mean pins every
+    band in aggregate).  Rows in itertools.product order (the reverse of the parquet row order, which the builder prepends)."""
+    import time
+    gl = np.array(prospect_grid()[::-1], dtype=np.float64)
+    gc = np.array(sailh_grid()[::-1], dtype=np.float64)
+    t0 = time.time()
+    with np.errstate(all="ignore"), Pool(8, initializer=_grid_init) as pool:
+        rc = pool.map(_grid_canopy_row, list(gc), chunksize=32)
+        print("sailh grid", len(rc), "%.0f s" % (time.time() - t0), flush=True)
+        rl = pool.map(_grid_leaf_row, list(gl), chunksize=16)
+        print("prospect grid", len(rl), "%.0f s" % (time.time() - t0), flush=True)
+    np.savez_compressed(os.path.join(HERE, "grids.npz"),
+                        leaf_grid=gl, leaf_probe_index=np.array(GRID_PROBES_LEAF), leaf_probes=np.array([r[0] for r in rl]),
+                        leaf_means=np.array([r[1] for r in rl]),
+                        canopy_grid=gc, canopy_probe_index=np.array(GRID_PROBES_CANOPY), canopy_probes=np.array([r[0] for r in rc]),
+                        canopy_means=np.array([r[1] for r in rc]))
+
 
 
 if __name__ == "__main__":

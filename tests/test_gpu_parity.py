@@ -28,11 +28,14 @@ def torch_mod():
 
 
 def test_native_library_is_loaded(torch_mod):
+    """the in-tree HIP library is what runs, and it was built from the sources next to it (a stale .so fails here)"""
     from spart_amd import _lib
     lib = _lib.load()
     assert lib is not None
     with open("/proc/self/maps") as f:
         assert "libspart_hip.so" in f.read()
+    assert _lib.build_id(lib) == _lib.expected_build_id()
+    assert len(_lib.build_id(lib)) == 12
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
@@ -76,41 +79,52 @@ def test_sailh_golden(golden, dtype, torch_mod):
         assert rel_err(o.cpu().numpy(), g[k], FLOOR[dtype]) < TOL[dtype], k
 
 
-def test_reference_test_grids_all_rows(golden, oracle, tables, torch_mod):
-    """The reference's own unit-test grids IN FULL (its tests draw 10 of these rows unless run with --all, and the parquet
-    files with the expected values are missing from the snapshot): the 6480-case PROSPECT grid
-    (tests/unit/test_PROSPECT/build_PROSPECT_tests.py:38-50) and the 8100-case SAILH grid
+def test_reference_test_grids_all_rows(golden, torch_mod):
+    """The reference's own unit-test grids IN FULL, refereed by the REFERENCE ITSELF (tests/golden/grids.npz: its
+    PROSPECT_5D / SAILH run over every case; 16 probe bands + the all-band mean of each spectrum -- its parquet files with
+    the expected values are missing from the snapshot and its tests draw 10 rows unless run with --all): the 6480-case
+    PROSPECT grid (tests/unit/test_PROSPECT/build_PROSPECT_tests.py:38-50) and the 8100-case SAILH grid
     (tests/unit/test_SAILH/build_SAILH_tests.py:87-101, default leaf / soil fixtures, dso = 0 hot-spot cases and the
-    non-physical |a| + |b| > 1 LIDFs included), HIP float64 through the C ABI against the oracle, with the reference's own
-    assertion precision: assert_almost_equal (7 decimals = 1.5e-7) on the leaf spectra, assert_array_almost_equal
-    (6 decimals = 1.5e-6) on the canopy spectra -- and float32 at 1e-4 of max(|ref|, 1e-2)."""
+    non-physical |a| + |b| > 1 LIDFs included), HIP float64 through the C ABI with the reference tests' own precision:
+    assert_almost_equal (7 decimals = 1.5e-7, test_PROSPECT.py:25-27) on the leaf spectra, assert_array_almost_equal
+    (6 decimals = 1.5e-6, test_SAILH.py:33-36) on the canopy spectra -- and float32 at 1e-4 of max(|ref|, 1e-2)."""
     import itertools
     from spart_amd import get_engine
     eng = get_engine(None, 0)
+    gg = golden["grids"]
     grid = np.array(list(itertools.product(range(10, 90, 10), (0.005, 0.015), (0.02, 0.06, 0.10), (0.0, 0.5, 1.0), (10, 20, 30),
                                            (10, 20, 30), (1.0, 1.5, 2.0, 2.5, 3.0))), dtype=np.float64)
-    assert grid.shape == (6480, 7)
-    leaf = np.concatenate([grid, np.zeros((6480, 2))], axis=1)            # LeafBiology(*row): PROT = CBC = 0
-    ref = oracle.prospect_5d(leaf, tables)
-    out = eng.prospect(list(leaf.T), "float64")
-    for got, want, name in zip(out, ref, ("refl", "tran", "kChlrel")):
-        assert np.max(np.abs(got.cpu().numpy() - want)) < 1.5e-7, name
-    out32 = eng.prospect(list(leaf.T), "float32")
-    for got, want, name in zip(out32, ref, ("refl", "tran", "kChlrel")):
-        assert rel_err(got.cpu().numpy(), want, 1e-2) < 1e-4, name
+    assert grid.shape == (6480, 7) and np.allclose(grid, gg["leaf_grid"], rtol=0, atol=1e-12)     # the fixture IS that grid
+    leaf = np.concatenate([gg["leaf_grid"], np.zeros((6480, 2))], axis=1)            # LeafBiology(*row): PROT = CBC = 0
+    pi = gg["leaf_probe_index"]
+    for dtype in ("float64", "float32"):
+        out = eng.prospect(list(leaf.T), dtype)
+        for j, (got, name) in enumerate(zip(out, ("refl", "tran", "kChlrel"))):
+            a = got.double().cpu().numpy()
+            if dtype == "float64":
+                assert np.max(np.abs(a[:, pi] - gg["leaf_probes"][:, j])) < 1.5e-7, name
+                assert np.max(np.abs(a.mean(axis=1) - gg["leaf_means"][:, j])) < 1.5e-7, name
+            else:
+                assert rel_err(a[:, pi], gg["leaf_probes"][:, j], 1e-2) < 1e-4, name
+                assert rel_err(a.mean(axis=1), gg["leaf_means"][:, j], 1e-2) < 1e-4, name
     # SAILH grid over the default leaf / soil fixtures (tests/conftest.py:48-112 of the reference = the golden file's spectra)
     g = golden["sailh"]
     can = np.array(list(itertools.product((1, 4, 7), (-1, -0.6, -0.2, 0.2, 0.6), (-1, -0.6, -0.2, 0.2, 0.6), (0.01, 0.06, 0.11, 0.16),
                                           (0, 30, 60), (0, 30, 60), (0, 80, 160))), dtype=np.float64)
-    assert can.shape == (8100, 7)
-    want = oracle.sailh(g["leaf_refl"][None], g["leaf_tran"][None], g["soil_refl"][None], can[:, :4], can[:, 4:], pso="gl")
-    got = eng.sailh(g["leaf_refl"][None], g["leaf_tran"][None], g["soil_refl"][None], list(can[:, :4].T), list(can[:, 4:].T), "float64")
-    for o, k in zip(got, ("rso", "rdo", "rsd", "rdd")):
-        assert np.max(np.abs(o.cpu().numpy() - want[k])) < 1.5e-6, k
-        assert rel_err(o.cpu().numpy(), want[k], 1e-3) < 1e-6, k        # (and the north-star tolerance)
-    got32 = eng.sailh(g["leaf_refl"][None], g["leaf_tran"][None], g["soil_refl"][None], list(can[:, :4].T), list(can[:, 4:].T), "float32")
-    for o, k in zip(got32, ("rso", "rdo", "rsd", "rdd")):
-        assert rel_err(o.cpu().numpy(), want[k], 1e-2) < 1e-4, k
+    assert can.shape == (8100, 7) and np.allclose(can, gg["canopy_grid"], rtol=0, atol=1e-12)
+    can = gg["canopy_grid"]
+    ci = gg["canopy_probe_index"]
+    for dtype in ("float64", "float32"):
+        got = eng.sailh(g["leaf_refl"][None], g["leaf_tran"][None], g["soil_refl"][None], list(can[:, :4].T), list(can[:, 4:].T), dtype)
+        for j, (o, k) in enumerate(zip(got, ("rso", "rdo", "rsd", "rdd"))):
+            a = o.double().cpu().numpy()
+            if dtype == "float64":
+                assert np.max(np.abs(a[:, ci] - gg["canopy_probes"][:, j])) < 1.5e-6, k
+                assert rel_err(a[:, ci], gg["canopy_probes"][:, j], 1e-3) < 1e-6, k        # (and the north-star tolerance)
+                assert np.max(np.abs(a.mean(axis=1) - gg["canopy_means"][:, j])) < 1.5e-6, k
+            else:
+                assert rel_err(a[:, ci], gg["canopy_probes"][:, j], 1e-2) < 1e-4, k
+                assert rel_err(a.mean(axis=1), gg["canopy_means"][:, j], 1e-2) < 1e-4, k
 
 
 @pytest.mark.parametrize("sensor", ["Sentinel2A-MSI", "Sentinel2B-MSI", "TerraAqua-MODIS", "LANDSAT7-ETM",
@@ -810,3 +824,92 @@ def test_edge_rows_golden(golden, torch_mod):
     assert phys.sum() > 60
     for k in ("R_TOC", "R_TOA", "L_TOA"):
         assert rel_err(o32[k].cpu().numpy()[phys], g[k][phys], COLFLOOR) < 1e-4, k
+
+
+MAT_FIELDS = ("leaf_refl", "leaf_tran", "leaf_kchl", "soil_refl", "soil_refl_dry", "rso", "rdo", "rsd", "rdd")
+
+
+def _probe_rows(B, chunk, rng):
+    """64 rows of a batch whose band kernel walks `chunk` samples per workgroup (spart_capi.hip pick_chunk): the front,
+    two workgroup (chunk) boundaries, the 32-sample constant-staging boundary inside two chunks, the ragged tail, and
+    random rows."""
+    nchunk = -(-B // chunk)
+    rows = list(range(0, 8))
+    for c in (3, nchunk // 2):
+        rows += list(range(c * chunk - 4, c * chunk + 4))
+    if chunk > 32:
+        for c in (5, nchunk - 2):
+            rows += list(range(c * chunk + 32 - 4, min(c * chunk + 32 + 4, (c + 1) * chunk)))
+    rows += list(range(B - 8, B))
+    rows = sorted(set(r for r in rows if 0 <= r < B))
+    extra = [int(r) for r in rng.choice(B, size=200, replace=False) if int(r) not in rows]
+    rows = sorted(rows + extra[:64 - len(rows)])
+    assert len(rows) == 64
+    return rows
+
+
+@pytest.mark.parametrize("dtype,B", [("float32", 300_001), ("float64", 270_001)])
+def test_materialised_and_user_soil_paths_at_size(oracle, tables, dtype, B, torch_mod):
+    """The store path of the fused kernel at a size where every part of its sample walk is exercised -- chunks of 37
+    (float32) / 33 (float64) samples per workgroup, i.e. a full 32-sample staging block + a short one, a ragged last chunk,
+    the per-sample row advance (off += pitch), the thermal-pad broadcast, the sample-major G / rsoil slots -- with all nine
+    spectrum arrays + rsoil + La + band_mean requested, for the padded and the dense row pitch, without (MAT = 1) and with
+    per-sample user dry-soil spectra read from HBM (MAT = 2; SoilParametersFromFile, bsm.py:42-43).  64 probe rows are
+    compared (a) with the oracle (leaf / soil / canopy spectra SPART.py:427-470, bsm.py:42-43, sailh.py:222-233 + the
+    columns) at the stage tests' tolerances and (b) BIT FOR BIT with the same rows evaluated as 64 one-sample batches;
+    the two pitches must agree bit for bit on everything, and band_mean must be the mean of the materialised rows."""
+    import spart_amd.engine as E
+    from spart_amd import workloads
+    torch = torch_mod
+    td = torch.float32 if dtype == "float32" else torch.float64
+    chunk = -(-B // 8192)
+    assert chunk > 32, "the batch must be large enough for more than one constant-staging block per workgroup"
+    rng = np.random.default_rng(31)
+    rows = _probe_rows(B, chunk, rng)
+    Ph = workloads.lhs_params(B, "full", seed=77)
+    P = torch.as_tensor(Ph.T.copy(), device="cuda:0")
+    ridx = torch.as_tensor(rows, device="cuda:0")
+    # per-sample dry-soil spectra: smooth, in (0.05, 0.6), different for every sample
+    gen = torch.Generator(device="cuda:0").manual_seed(9)
+    abc = torch.rand((B, 3), generator=gen, device="cuda:0", dtype=torch.float64)
+    x = torch.arange(2001, device="cuda:0", dtype=torch.float64)[None, :]
+    fields = MAT_FIELDS + ("rsoil", "La", "band_mean")
+    tol, fl = TOL[dtype], FLOOR[dtype]
+    pad = E.Engine("Sentinel2A-MSI", 0)
+    dense = E.Engine("Sentinel2A-MSI", 0, row_pitch=None)
+    for use_rdry in (False, True):
+        rd = None
+        if use_rdry:
+            rd = (0.08 + 0.25 * abc[:, 0:1] + 0.2 * abc[:, 1:2] * (x / 2000.0) + 0.03 * abc[:, 2:3] * torch.sin(x / 90.0)).to(td)
+        ref = oracle.spart_run(Ph[rows], "Sentinel2A-MSI", tables, pso="gl", full=True,
+                               rdry=None if rd is None else rd[ridx].double().cpu().numpy())
+        rho, tau = oracle.pad_leaf(ref["leaf_refl"], ref["leaf_tran"])
+        expect = dict(leaf_refl=rho, leaf_tran=tau, leaf_kchl=ref["kChlrel"], soil_refl=oracle.pad_soil(ref["soil_refl"]),
+                      soil_refl_dry=ref["soil_refl_dry"], rso=ref["rso"], rdo=ref["rdo"], rsd=ref["rsd"], rdd=ref["rdd"],
+                      rsoil=ref["rsoil"], La=ref["La"], R_TOC=ref["R_TOC"], R_TOA=ref["R_TOA"], L_TOA=ref["L_TOA"])
+        got = {}
+        for name, eng in (("padded", pad), ("dense", dense)):
+            out = eng.run(P, dtype, materialize=fields, rdry=rd)
+            torch.cuda.synchronize()
+            assert out["rso"].stride(0) == (E.ROW_PITCH[0] if name == "padded" else 2162)
+            # band_mean (4, 2162) = mean over ALL samples of the materialised canopy rows (every row took part)
+            for q, k in enumerate(("rso", "rdo", "rsd", "rdd")):
+                m = out[k].double().mean(0)
+                assert float(((out["band_mean"][q].double() - m).abs() / m.abs().clamp_min(1e-3)).max()) < (2e-5 if dtype == "float32" else 1e-10), (name, k)
+            assert all(bool(torch.isfinite(out[k]).all()) for k in MAT_FIELDS), name
+            got[name] = {k: out[k][ridx].cpu().numpy() for k in expect}
+            del out
+            torch.cuda.empty_cache()
+        for k in expect:
+            assert np.array_equal(got["padded"][k], got["dense"][k]), (use_rdry, k)
+            floor = COLFLOOR if k in ("R_TOC", "R_TOA", "L_TOA", "rsoil", "La") else fl
+            assert rel_err(got["padded"][k], expect[k], floor) < tol, (use_rdry, k)
+        # the same rows as one-sample batches (chunk = 1: no walk at all)
+        for j, r in enumerate(rows):
+            one = pad.run(P[:, r:r + 1].contiguous(), dtype, materialize=fields, rdry=None if rd is None else rd[r:r + 1])   # (same kernel variant)
+            for k in expect:
+                assert np.array_equal(one[k].cpu().numpy()[0], got["padded"][k][j]), (use_rdry, r, k)
+        del rd
+    pad.release_workspace()
+    dense.release_workspace()
+    torch.cuda.empty_cache()

@@ -52,6 +52,27 @@ def test_sailh(oracle, golden, pso):
         assert rel_err(c[k], g[k], 1e-9) < 1e-10, k
 
 
+def test_reference_unit_test_grids(oracle, tables, golden):
+    """The reference's own unit-test grids (6480 PROSPECT cases, build_PROSPECT_tests.py:38-50; 8100 SAILH cases,
+    build_SAILH_tests.py:87-101), expected values from the REFERENCE ITSELF over the whole grids (grids.npz: 16 probe bands +
+    the all-band mean of every spectrum; its parquet files are missing from the snapshot).  Here every 5th case (the CPU
+    suite's time budget; the GPU test compares all 14 580), at the reference tests' own precision (test_PROSPECT.py:25-27:
+    7 decimals, test_SAILH.py:33-36: 6 decimals) -- measured: 1.4e-8 (its QUADPACK E1) and 2e-15."""
+    g = golden["grids"]
+    sel = slice(0, None, 5)
+    lg = g["leaf_grid"][sel]
+    out = oracle.prospect_5d(np.concatenate([lg, np.zeros((len(lg), 2))], axis=1), tables)
+    for j, (o, name) in enumerate(zip(out, ("refl", "tran", "kChlrel"))):
+        assert np.max(np.abs(o[:, g["leaf_probe_index"]] - g["leaf_probes"][sel, j])) < 1.5e-7, name
+        assert np.max(np.abs(o.mean(axis=1) - g["leaf_means"][sel, j])) < 1.5e-7, name
+    s = golden["sailh"]
+    cg = g["canopy_grid"][sel]
+    c = oracle.sailh(s["leaf_refl"][None], s["leaf_tran"][None], s["soil_refl"][None], cg[:, :4], cg[:, 4:], pso="gl")
+    for j, k in enumerate(("rso", "rdo", "rsd", "rdd")):
+        assert np.max(np.abs(c[k][:, g["canopy_probe_index"]] - g["canopy_probes"][sel, j])) < 1e-12, k
+        assert np.max(np.abs(c[k].mean(axis=1) - g["canopy_means"][sel, j])) < 1e-12, k
+
+
 def test_sailh_length_check(oracle):
     with pytest.raises(RuntimeError, match="2162"):
         oracle.sailh(np.zeros((1, 2001)), np.zeros((1, 2001)), np.zeros((1, 2001)), [[3, 0, 0, 0.05]], [[40, 0, 0]])
