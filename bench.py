@@ -272,7 +272,7 @@ def extras(torch, args, dev):
 
 MAT_FIELDS = ("leaf_refl", "leaf_tran", "leaf_kchl", "soil_refl", "soil_refl_dry", "rso", "rdo", "rsd", "rdd")
 MAT_BYTES_F32 = (7 * 2162 + 2 * 2001) * 4          # +75 256 B per spectrum, float32
-LUT_BOUND = "valu"                                 # k_lut_scan2: packed fp32 FMAs with the LUT rows wave-uniform
+LUT_BOUND = "mfma"                                 # k_lut_scan_mfma: exact-f32 v_mfma_f32_32x32x2_f32
 
 
 def mode_records(torch, args, dev):
@@ -346,7 +346,7 @@ def mode_records(torch, args, dev):
     d = ((lut.double()[None, :, :] - obs[:64].double()[:, None, :]) ** 2).sum(-1)
     bf_cost, bf = d.min(1)
     got_cost = ((lut[idx[:64]].double() - obs[:64].double()) ** 2).sum(-1)
-    nbp = 16 if lut.shape[1] <= 15 else 32
+    nbp = 2 * next(k for k in (4, 7, 8, 11, 16) if k >= (lut.shape[1] + 2) // 2)     # K of the GEMM: nb + 1 (norm slot), in MFMA steps of 2
     cmp_s = lut.shape[0] * M / sec
     rec["lut_invert"] = {
         "workload": f"spart_lut_nearest: {lut.shape[0]}-row LUT (R_TOC of the config-4 table, {lut.shape[1]} bands) x {M} noisy observations, fp32",
@@ -356,8 +356,9 @@ def mode_records(torch, args, dev):
         "roofline": {"bound": LUT_BOUND, "achieved": cmp_s * 2 * nbp / 1e12,
                      "peak": VALU_PEAK_TFLOPS["float32"], "unit": "TFLOP/s", "frac": cmp_s * 2 * nbp / 1e12 / VALU_PEAK_TFLOPS["float32"],
                      "flops_per_comparison": 2 * nbp,
-                     "note": f"2 x {nbp} flops per comparison (rows padded to {nbp} values incl. the norm slot); peak = fp32 vector / "
-                             "exact-f32 MFMA peak, both 157.3 TF (MI355X_MICROARCH.md); whole call timed (prep + scan + reduce)"}}
+                     "note": f"cost(b, m) = sum_k A[b][k] Bq[k][m], K = {nbp} (nb + 1 incl. the norm slot, in MFMA steps of 2): 2 x {nbp} flops "
+                             "per comparison on v_mfma_f32_32x32x2_f32 (exact f32); peak = the f32-input MFMA peak 157.3 TF "
+                             "(MI355X_MICROARCH.md: equal to the vector peak); whole call timed (prep + scan + reduce)"}}
     del lut, obs, idx, cost, d, pick
     torch.cuda.empty_cache()
     # --- LUT generation end to end: host parameter table in, host columns out (PCIe-inclusive; never the headline)

@@ -405,9 +405,10 @@ static int lut_slices(int64_t M) {
 
 static int lut_nbp(int nb) { return nb <= 15 ? 16 : 32; }
 
-template <typename T>
-static int lut_impl(spart_ctx* ctx, int64_t B, int nb, const void* lut, int64_t M, const void* obs, const void* weights,
-                    int64_t* best_idx, void* best_cost, char* wsp, hipStream_t st) {
+// float64: vector-ALU scan (k_lut_scan), one observation per lane
+static int lut_impl_f64(spart_ctx* ctx, int64_t B, int nb, const void* lut, int64_t M, const void* obs, const void* weights,
+                        int64_t* best_idx, void* best_cost, char* wsp, hipStream_t st) {
+  using T = double;
   const int nslice = lut_slices(M);
   const int nbp = lut_nbp(nb);
   T* padded = (T*)wsp;
@@ -415,28 +416,63 @@ static int lut_impl(spart_ctx* ctx, int64_t B, int nb, const void* lut, int64_t 
   int64_t* pi = (int64_t*)((char*)pc + align_up((size_t)nslice * M * sizeof(T)));
   dim3 gprep((unsigned)((B + 255) / 256));
   dim3 grid((unsigned)((M + 255) / 256), (unsigned)nslice);
-  dim3 grid2((unsigned)((M + 511) / 512), (unsigned)nslice);       // float32: two observations per lane
-  const bool pk = sizeof(T) == 4 && (B + nslice - 1) / nslice < (int64_t)2000000000LL;
   if (nbp == 16) {
     hipLaunchKernelGGL((k_lut_prep<T, 16>), gprep, dim3(256), 0, st, (const T*)lut, (const T*)weights, nb, B, padded);
-    if (pk)
-      hipLaunchKernelGGL((k_lut_scan2<16>), grid2, dim3(256), 0, st, (const float*)padded, (const float*)obs,
-                         (const float*)weights, nb, B, M, nslice, (float*)pc, pi);
-    else
-      hipLaunchKernelGGL((k_lut_scan<T, 16>), grid, dim3(256), 0, st, (const T*)padded, (const T*)obs, (const T*)weights,
-                         nb, B, M, nslice, pc, pi);
+    hipLaunchKernelGGL((k_lut_scan<T, 16>), grid, dim3(256), 0, st, (const T*)padded, (const T*)obs, (const T*)weights,
+                       nb, B, M, nslice, pc, pi);
   } else {
     hipLaunchKernelGGL((k_lut_prep<T, 32>), gprep, dim3(256), 0, st, (const T*)lut, (const T*)weights, nb, B, padded);
-    if (pk)
-      hipLaunchKernelGGL((k_lut_scan2<32>), grid2, dim3(256), 0, st, (const float*)padded, (const float*)obs,
-                         (const float*)weights, nb, B, M, nslice, (float*)pc, pi);
-    else
-      hipLaunchKernelGGL((k_lut_scan<T, 32>), grid, dim3(256), 0, st, (const T*)padded, (const T*)obs, (const T*)weights,
-                         nb, B, M, nslice, pc, pi);
+    hipLaunchKernelGGL((k_lut_scan<T, 32>), grid, dim3(256), 0, st, (const T*)padded, (const T*)obs, (const T*)weights,
+                       nb, B, M, nslice, pc, pi);
   }
   HIP_TRY(ctx, hipGetLastError());
   hipLaunchKernelGGL((k_lut_reduce<T>), dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, (const T*)pc, (const int64_t*)pi,
                      (const T*)lut, (const T*)obs, (const T*)weights, nb, M, nslice, best_idx, (T*)best_cost);
+  HIP_TRY(ctx, hipGetLastError());
+  return SPART_OK;
+}
+
+// float32: the scan is a GEMM with K = nb + 1 on the exact-f32 matrix cores (k_lut_scan_mfma).  K steps of 2:
+// KS = ceil((nb + 1) / 2) MFMAs per 32 x 32 comparisons, rounded up to one of the compiled variants.
+static int lut_ks(int nb) {
+  const int need = (nb + 2) / 2;
+  for (int ks : {4, 7, 8, 11, 16})
+    if (ks >= need) return ks;
+  return 16;
+}
+// workgroups = ceil(M / 512) x nslice; slices are whole 32-row tiles
+static int lut_slices_mfma(int64_t M, int64_t ntile) {
+  const int64_t mg = (M + 32 * LUT_TO * 4 - 1) / (32 * LUT_TO * 4);
+  int64_t n = (4096 + mg - 1) / mg;
+  if (n > ntile) n = ntile;
+  if (n > 1024) n = 1024;
+  if (n < 1) n = 1;
+  return (int)n;
+}
+static int lut_impl_f32(spart_ctx* ctx, int64_t B, int nb, const void* lut, int64_t M, const void* obs, const void* weights,
+                        int64_t* best_idx, void* best_cost, char* wsp, hipStream_t st) {
+  const int ks = lut_ks(nb);
+  const int64_t ntile = (B + 31) / 32;
+  const int nslice = lut_slices_mfma(M, ntile);
+  float* tiles = (float*)wsp;
+  float* pc = (float*)(wsp + align_up((size_t)ntile * ks * 64 * 4));
+  int* pt = (int*)((char*)pc + align_up((size_t)nslice * 2 * M * 4));
+  const dim3 gprep((unsigned)((ntile * ks * 64 + 255) / 256));
+  const dim3 grid((unsigned)((M + 32 * LUT_TO * 4 - 1) / (32 * LUT_TO * 4)), (unsigned)nslice);
+#define SPART_LUT_KS(K)                                                                                                    \
+  case K:                                                                                                                  \
+    hipLaunchKernelGGL((k_lut_prep_mfma<K>), gprep, dim3(256), 0, st, (const float*)lut, (const float*)weights, nb, B, ntile, \
+                       tiles);                                                                                             \
+    hipLaunchKernelGGL((k_lut_scan_mfma<K>), grid, dim3(256), 0, st, (const float*)tiles, (const float*)obs,               \
+                       (const float*)weights, nb, ntile, M, nslice, pc, pt);                                               \
+    break;
+  switch (ks) {
+    SPART_LUT_KS(4) SPART_LUT_KS(7) SPART_LUT_KS(8) SPART_LUT_KS(11) SPART_LUT_KS(16)
+  }
+#undef SPART_LUT_KS
+  HIP_TRY(ctx, hipGetLastError());
+  hipLaunchKernelGGL(k_lut_reduce_tiles, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, (const float*)pc, (const int*)pt,
+                     (const float*)lut, (const float*)obs, (const float*)weights, nb, B, M, 2 * nslice, best_idx, (float*)best_cost);
   HIP_TRY(ctx, hipGetLastError());
   return SPART_OK;
 }
@@ -782,9 +818,13 @@ int spart_run_batch(spart_ctx* ctx, int dtype, int64_t B, const double* const pa
 
 size_t spart_lut_workspace_bytes(int dtype, int64_t B, int nb, int64_t M) {
   if (B <= 0 || M <= 0 || nb < 1) return 0;
-  size_t es = dtype == SPART_F64 ? 8 : 4;
+  if (dtype == SPART_F32) {
+    const int64_t ntile = (B + 31) / 32;
+    const int nslice = lut_slices_mfma(M, ntile);
+    return align_up((size_t)ntile * lut_ks(nb) * 64 * 4) + 2 * align_up((size_t)nslice * 2 * M * 4);
+  }
   int nslice = lut_slices(M);
-  return align_up((size_t)B * lut_nbp(nb) * es) + align_up((size_t)nslice * M * es) + align_up((size_t)nslice * M * 8);
+  return align_up((size_t)B * lut_nbp(nb) * 8) + align_up((size_t)nslice * M * 8) + align_up((size_t)nslice * M * 8);
 }
 
 int spart_lut_nearest(spart_ctx* ctx, int dtype, int64_t B, int nb, const void* lut, int64_t M, const void* obs,
@@ -801,8 +841,8 @@ int spart_lut_nearest(spart_ctx* ctx, int dtype, int64_t B, int nb, const void* 
     return fail(ctx, SPART_ERR_WORKSPACE, "spart_lut_nearest: workspace of %zu bytes needed, %zu given", need, workspace_bytes);
   DeviceGuard guard(ctx->device);
   hipStream_t st = (hipStream_t)stream;
-  return dtype == SPART_F32 ? lut_impl<float>(ctx, B, nb, lut, M, obs, weights, best_idx, best_cost, (char*)workspace, st)
-                            : lut_impl<double>(ctx, B, nb, lut, M, obs, weights, best_idx, best_cost, (char*)workspace, st);
+  return dtype == SPART_F32 ? lut_impl_f32(ctx, B, nb, lut, M, obs, weights, best_idx, best_cost, (char*)workspace, st)
+                            : lut_impl_f64(ctx, B, nb, lut, M, obs, weights, best_idx, best_cost, (char*)workspace, st);
 }
 
 }  // extern "C"

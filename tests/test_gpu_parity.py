@@ -707,7 +707,8 @@ def test_lut_on_disk_parquet_leg(golden, tmp_path, torch_mod):
         assert rel_err(tab, g[f"lhs_full/Sentinel2A-MSI/{k}"], COLFLOOR) < 1e-6, k
 
 
-@pytest.mark.parametrize("dtype,nb", [("float32", 13), ("float64", 13), ("float32", 6), ("float32", 21)])
+@pytest.mark.parametrize("dtype,nb", [("float32", 13), ("float64", 13), ("float32", 6), ("float32", 21), ("float32", 15),
+                                      ("float32", 31), ("float32", 1), ("float64", 31)])
 def test_lut_inversion_matches_brute_force(dtype, nb, torch_mod):
     """spart_lut_nearest against a numpy brute-force search (weighted and unweighted, ragged sizes, NaN rows)."""
     from spart_amd import get_engine
@@ -728,9 +729,36 @@ def test_lut_inversion_matches_brute_force(dtype, nb, torch_mod):
         true_idx, true_cost = d.argmin(axis=1), d.min(axis=1)
         tol = 1e-6 if dtype == "float32" else 1e-12
         assert np.all(d[np.arange(M), idx] <= true_cost + tol)            # the chosen row is a minimiser (ties aside)
-        assert np.mean(idx == true_idx) > 0.999
+        if nb > 1:                                    # (one band: 20 000 rows 3e-5 apart, squared distances tie at the tolerance)
+            assert np.mean(idx == true_idx) > 0.999
         assert np.max(np.abs(cost - true_cost)) < 10 * tol
         assert list(idx[:5]) == [100, 101, 102, 103, 104] and np.all(cost[:5] == 0.0)    # exact members: the cost is recomputed from the row
+
+
+def test_lut_inversion_small_and_tied(torch_mod):
+    """Sizes below one MFMA tile / one observation block, duplicate rows (ties go to the lowest row index, also across
+    32-row tiles and across slices), an all-NaN LUT and a NaN observation (index -1, cost inf)."""
+    from spart_amd import get_engine
+    eng = get_engine(None, 0)
+    rng = np.random.default_rng(5)
+    for B, M in ((1, 1), (20, 3), (33, 130), (4099, 1), (70_000, 5)):
+        lut = rng.uniform(0.0, 0.6, (B, 13)).astype(np.float32)
+        obs = lut[rng.integers(0, B, M)] + rng.normal(0, 0.01, (M, 13)).astype(np.float32)
+        idx, cost = eng.lut_nearest(lut, obs)
+        d = ((lut.astype(np.float64)[None] - obs.astype(np.float64)[:, None]) ** 2).sum(-1)
+        assert np.all(d[np.arange(M), idx.cpu().numpy()] <= d.min(axis=1) + 1e-6), (B, M)
+    lut = rng.uniform(0.0, 0.6, (5000, 13)).astype(np.float32)
+    lut[[40, 700, 4100]] = lut[7]                     # the same row in three other tiles
+    lut[3] = lut[2]
+    for dtype in ("float32", "float64"):
+        idx, cost = eng.lut_nearest(lut, lut[[7, 700, 3, 2]], dtype=dtype)
+        assert idx.cpu().tolist() == [7, 7, 2, 2] and float(cost.abs().max()) == 0.0, dtype
+        obs = lut[:3].copy()
+        obs[1, 4] = np.nan
+        idx, cost = eng.lut_nearest(lut, obs, dtype=dtype)
+        assert idx.cpu().tolist() == [0, -1, 2] and np.isinf(cost.cpu().numpy()[1]), dtype
+        idx, cost = eng.lut_nearest(np.full((100, 13), np.nan, dtype=np.float32), lut[:2], dtype=dtype)
+        assert idx.cpu().tolist() == [-1, -1] and bool(np.isinf(cost.cpu().numpy()).all()), dtype
 
 
 def test_lut_inversion_recovers_parameters(torch_mod):
