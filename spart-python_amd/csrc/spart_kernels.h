@@ -148,8 +148,15 @@ template <typename T, typename C> __device__ __forceinline__ CanopyPar<T> load_c
 // the "saddr" form of global_store.  Keeping the per-array bases in SGPRs (instead of one 64-bit per-lane pointer
 // per output array, 22 VGPRs for 11 arrays) is what lets the materialising kernel run at the occupancy of the
 // columns-only one.
+#ifndef SPART_NT_STORES
+#define SPART_NT_STORES 0
+#endif
 template <typename T> __device__ __forceinline__ void store_row(T* row, unsigned byte_off, T v) {
+#if SPART_NT_STORES
+  __builtin_nontemporal_store(v, reinterpret_cast<T*>(reinterpret_cast<char*>(row) + byte_off));
+#else
   *reinterpret_cast<T*>(reinterpret_cast<char*>(row) + byte_off) = v;
+#endif
 }
 
 template <typename T> struct MatPtrs {
@@ -189,7 +196,8 @@ void k_bands(const T* __restrict__ tab, const T* __restrict__ cst, int64_t Bp,
   int tile;
   int64_t ck;
   xcd_map(blockIdx.x, tile, ck);
-  if (ck * chunk >= B) return;
+  if (ck * chunk >= B) return;                         // (block-uniform)
+  if (sizeof(T) == 8) stage_f64_tables();              // exp / log tables of the float64 band arithmetic -> LDS
   const int band = tile * TILE + threadIdx.x;          // 0..2047
   const bool active = band < NEVAL;
   const bool thermal = band == NWL;                    // the single thermal evaluation
@@ -342,6 +350,7 @@ __global__ __launch_bounds__(256) void k_slots(const T* __restrict__ tab, const 
                                                const int* __restrict__ slot_band, T* __restrict__ G,
                                                T* __restrict__ gsoil, const TR* __restrict__ rdry_in, int po, int64_t B,
                                                int nslot) {
+  if (sizeof(T) == 8) stage_f64_tables();                      // (before any thread leaves: it ends with a barrier)
   const unsigned per = 8u * (unsigned)nslot, within = blockIdx.x % per;
   const int q = (int)(within >> 3);
   const int64_t s = ((int64_t)(blockIdx.x / per) * 8 + (within & 7u)) * blockDim.x + threadIdx.x;
@@ -419,6 +428,7 @@ __global__ __launch_bounds__(TILE) void k_prospect(const T* __restrict__ tab, co
   int64_t ck;
   xcd_map(blockIdx.x, tile, ck);
   if (ck * chunk >= B) return;
+  if (sizeof(T) == 8) stage_f64_tables();
   const int band = tile * TILE + threadIdx.x;
   const bool active = band < NWL;
   const BandTab<T> tb = load_tab(tab, active ? band : NWL - 1);
@@ -451,6 +461,7 @@ __global__ __launch_bounds__(TILE) void k_bsm(const T* __restrict__ tab, const T
   int64_t ck;
   xcd_map(blockIdx.x, tile, ck);
   if (ck * chunk >= B) return;
+  if (sizeof(T) == 8) stage_f64_tables();
   const int band = tile * TILE + threadIdx.x;
   const bool active = band < NWL;
   const BandTab<T> tb = load_tab(tab, active ? band : NWL - 1);
@@ -480,6 +491,7 @@ __global__ __launch_bounds__(TILE) void k_sailh(const T* __restrict__ cst, int64
                                                 T* __restrict__ o_rdo, T* __restrict__ o_rsd, T* __restrict__ o_rdd) {
   const int tile = blockIdx.x % NTILE_FULL;
   const int64_t ck = blockIdx.x / NTILE_FULL;
+  if (sizeof(T) == 8) stage_f64_tables();
   const int band = tile * TILE + threadIdx.x;
   const bool active = band < NWLS;
   const int64_t s0 = ck * chunk;

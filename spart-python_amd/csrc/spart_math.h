@@ -47,6 +47,7 @@
 #endif
 
 #include "spart_e3_coeffs.h"
+#include "spart_f64_tables.h"
 
 namespace spart {
 
@@ -175,23 +176,45 @@ __device__ __forceinline__ double spart_horner(double p, double x, double c_unif
   return __builtin_fma(p, x, c_uniform);
 #endif
 }
-// exp / log for the float64 band arithmetic (device, SPART_FAST_MATH): the usual range reductions with their polynomial
-// coefficients in constant memory (scalar loads -> SGPR operands, no VGPRs parked on constants, no copy before each
-// Horner step as with the library versions).  exp(x) is 0 below x = -745 (including -inf), NaN
-// propagates; log is only called with positive finite arguments.  Relative error <= 2e-16.
+// exp / log for the float64 arithmetic (device, SPART_FAST_MATH).
+//  * exp_poly: range reduction to |r| <= ln2/2 + Taylor to r^13, coefficients in constant memory (scalar loads -> SGPR
+//    operands).  Needs no table: the sample-level prelude (one lane per sample, no workgroup staging) uses it.
+//  * exp / exp2 / log of the BAND kernels: table-driven.  e^x = 2^(k >> 8) T[k & 255] e^r with T[j] = 2^(j/256) and
+//    |r| <= ln2/512 (Taylor to r^4, remainder 4e-17): 17 instructions, 3 of them 32-bit integer, instead of 22 float64
+//    ones; ln x = e ln2 + L[i] + log1p(z) with i = the top 8 mantissa bits, z = m R[i] - 1, |z| <= 1/512 (Taylor to z^6,
+//    remainder 8e-18 relative): 15 instructions (5 of them 32-bit) instead of 27 -- and no reciprocal.  Both tables
+//    (csrc/spart_f64_tables.h, mpmath) sit in LDS: 6 KB per workgroup, staged by stage_f64_tables() at kernel entry;
+//    the lookups are per-lane ds_reads (neighbouring bands mostly hit the same entry: broadcast).  EVERY kernel that
+//    evaluates band arithmetic in float64 must call stage_f64_tables() first.
+//    exp(x) is 0 below x = -745 (including -inf), NaN propagates; log is only called with positive finite normal
+//    arguments (a NaN stays a NaN).  Relative error <= 3e-16 (exp), absolute <= 3e-16 / relative <= 2e-15 away from
+//    x = 1 (log).
 __device__ __constant__ double c_EXP_F64[12] = {1.0 / 2, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320,
                                                 1.0 / 362880, 1.0 / 3628800, 1.0 / 39916800, 1.0 / 479001600, 1.0 / 6227020800.0};
-__device__ __constant__ double c_LOG_F64[9] = {1.0 / 3, 1.0 / 5, 1.0 / 7, 1.0 / 9, 1.0 / 11, 1.0 / 13, 1.0 / 15, 1.0 / 17, 1.0 / 19};
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ const double g_F64_EXP_TAB[F64_EXP_TAB] = SPART_F64_EXP_TABLE;
+__device__ const double g_F64_LOG_TAB[2 * F64_LOG_TAB] = SPART_F64_LOG_TABLE;
+__shared__ __attribute__((aligned(16))) double s_f64_exp_tab[F64_EXP_TAB];
+__shared__ __attribute__((aligned(16))) double s_f64_log_tab[2 * F64_LOG_TAB];
+// all threads of the workgroup; ends with a barrier
+__device__ __forceinline__ void stage_f64_tables() {
+  for (int i = threadIdx.x; i < F64_EXP_TAB; i += blockDim.x) s_f64_exp_tab[i] = g_F64_EXP_TAB[i];
+  for (int i = threadIdx.x; i < 2 * F64_LOG_TAB; i += blockDim.x) s_f64_log_tab[i] = g_F64_LOG_TAB[i];
+  __syncthreads();
+}
+#else
+__device__ __forceinline__ void stage_f64_tables() {}     // (host pass of hipcc: declaration only)
+#endif
 #endif
 
 template <> struct Mx<double> {
 #if defined(__HIP_DEVICE_COMPILE__) && defined(SPART_FAST_MATH)
-  static SPART_HD double exp_scaled(double x, double inv_ln_b, double ln_b_hi, double ln_b_lo) {
-    // b^k * e^r with k = rint(x / ln 2), |r| <= ln 2 / 2: Taylor to r^13 (r^14/14! < 4e-18)
+  static SPART_HD double exp_poly(double x) {
+    // 2^k * e^r with k = rint(x / ln 2), |r| <= ln 2 / 2: Taylor to r^13 (r^14/14! < 4e-18)
     x = (x < -800.0) ? -800.0 : x;                          // e^-800 underflows to 0 below; a NaN stays a NaN
-    const double k = __builtin_rint(x * inv_ln_b);
-    double r = __builtin_fma(-k, ln_b_hi, x);
-    r = __builtin_fma(-k, ln_b_lo, r);
+    const double k = __builtin_rint(x * 1.4426950408889634);
+    double r = __builtin_fma(-k, 6.93147180369123816490e-01, x);
+    r = __builtin_fma(-k, 1.90821492927058770002e-10, r);
     spart_cdp ce = spart_fresh(c_EXP_F64);
     double p = ce[11];
 #pragma unroll
@@ -199,34 +222,44 @@ template <> struct Mx<double> {
     p = __builtin_fma(p * r, r, r);                       // r + r^2 (1/2 + ...)
     return __builtin_ldexp(1.0 + p, (int)k);
   }
-  static SPART_HD double exp(double x) {
-    return exp_scaled(x, 1.4426950408889634, 6.93147180369123816490e-01, 1.90821492927058770002e-10);
+  // 2^(k/256) e^r, k integral (as a double), |r| <= ln2/512
+  static SPART_HD double exp_finish(double k, double r) {
+    const int ki = (int)k;                                 // (NaN -> 0: r is NaN then, and so is the result)
+    const double t = s_f64_exp_tab[ki & (F64_EXP_TAB - 1)];
+    double p = __builtin_fma(r, 1.0 / 24.0, 1.0 / 6.0);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r * r, r);                        // e^r - 1
+    return __builtin_ldexp(__builtin_fma(t, p, t), ki >> 8);
   }
-  static SPART_HD double exp2(double x) {                  // 2^x = e^(x ln 2)
-    const double k = __builtin_rint(x);
-    const double r = (x - k) * 0.6931471805599453;
-    spart_cdp ce = spart_fresh(c_EXP_F64);
-    double p = ce[11];
-#pragma unroll
-    for (int i = 10; i >= 0; --i) p = spart_horner(p, r, ce[i]);
-    p = __builtin_fma(p * r, r, r);
-    return __builtin_ldexp(1.0 + p, (int)k);
+  static SPART_HD double exp(double x) {
+    x = (x < -800.0) ? -800.0 : x;                          // e^-800 underflows to 0 in ldexp; a NaN stays a NaN
+    const double k = __builtin_rint(x * 369.32993046757463);             // 256 / ln 2
+    double r = __builtin_fma(-k, 0.0027076061737716373, x);              // ln2/256, high part (33 bits: k * hi is exact)
+    r = __builtin_fma(-k, 2.9064910585985925e-13, r);                    // low part
+    return exp_finish(k, r);
+  }
+  static SPART_HD double exp2(double x) {                  // 2^x = 2^(k/256) e^((256 x - k) ln2 / 256)
+    const double t = x * 256.0;
+    const double k = __builtin_rint(t);
+    return exp_finish(k, (t - k) * 0.0027076061740622863);               // ln2 / 256
   }
   static SPART_HD double log(double x) {
-    // x = m 2^e with m in [sqrt(1/2), sqrt(2)); ln m = 2 atanh(s), s = (m - 1)/(m + 1), |s| <= 0.172 (s^21/21 < 5e-18)
-    int e;
-    double m = __builtin_frexp(x, &e);                     // m in [0.5, 1)
-    if (m < 0.7071067811865476) { m *= 2.0; e -= 1; }
-    const double s = (m - 1.0) * rcp(m + 1.0), s2 = s * s;
-    spart_cdp cl = spart_fresh(c_LOG_F64);
-    double p = cl[8];
-#pragma unroll
-    for (int i = 7; i >= 0; --i) p = spart_horner(p, s2, cl[i]);
-    p = __builtin_fma(p * s2, s, s);                       // s + s^3 (1/3 + ...)
-    const double ed = (double)e;
-    return __builtin_fma(ed, 6.93147180369123816490e-01, __builtin_fma(ed, 1.90821492927058770002e-10, 2.0 * p));
+    const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+    const unsigned hi = (unsigned)(u >> 32);
+    const int e = (int)(hi >> 20) - 1023;
+    const unsigned i = (hi >> 12) & (unsigned)(F64_LOG_TAB - 1);
+    const double m = __longlong_as_double((long long)((u & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull));   // [1, 2)
+    const double R = s_f64_log_tab[2 * i], L = s_f64_log_tab[2 * i + 1];  // one ds_read_b128
+    const double z = __builtin_fma(m, R, -1.0) + x * 0.0;   // (x * 0: a NaN / inf argument gives NaN instead of a finite value)
+    double q = __builtin_fma(z, -1.0 / 6.0, 0.2);
+    q = __builtin_fma(q, z, -0.25);
+    q = __builtin_fma(q, z, 1.0 / 3.0);
+    q = __builtin_fma(q, z, -0.5);
+    const double p = __builtin_fma(z * z, q, z);           // log1p(z)
+    return __builtin_fma((double)e, 0.6931471805599453, L + p);
   }
 #else
+  static SPART_HD double exp_poly(double x) { return ::exp(x); }
   static SPART_HD double exp(double x) { return ::exp(x); }
   static SPART_HD double exp2(double x) { return ::exp2(x); }
   static SPART_HD double log(double x) { return ::log(x); }
@@ -277,27 +310,36 @@ template <> struct Mx<double> {
 #endif
   }
   // 1 - e^-z, z >= 0: Taylor below 0.02 (z^9/9! < 2e-21), direct above (cancellation <= 1e-16/0.02 relative)
+  static SPART_HD double omen_taylor(double z) {
+    double p = -1.0 / 40320.0;
+    p = p * z + 1.0 / 5040.0;
+    p = p * z - 1.0 / 720.0;
+    p = p * z + 1.0 / 120.0;
+    p = p * z - 1.0 / 24.0;
+    p = p * z + 1.0 / 6.0;
+    p = p * z - 0.5;
+    p = p * z + 1.0;
+    return z * p;
+  }
   static SPART_HD double one_minus_exp_neg(double z) {
 #if defined(SPART_FAST_MATH)
-    if (z < 0.02) {
-      double p = -1.0 / 40320.0;
-      p = p * z + 1.0 / 5040.0;
-      p = p * z - 1.0 / 720.0;
-      p = p * z + 1.0 / 120.0;
-      p = p * z - 1.0 / 24.0;
-      p = p * z + 1.0 / 6.0;
-      p = p * z - 0.5;
-      p = p * z + 1.0;
-      return z * p;
-    }
+    if (z < 0.02) return omen_taylor(z);
     return 1.0 - exp(-z);
+#else
+    return -::expm1(-z);
+#endif
+  }
+  // (the prelude's form: no table, see exp_poly)
+  static SPART_HD double one_minus_exp_neg_poly(double z) {
+#if defined(SPART_FAST_MATH)
+    return (z < 0.02) ? omen_taylor(z) : 1.0 - exp_poly(-z);
 #else
     return -::expm1(-z);
 #endif
   }
   static SPART_HD double one_minus_exp_neg(double z, double ez) {
 #if defined(SPART_FAST_MATH)
-    return (z < 0.02) ? one_minus_exp_neg(z) : 1.0 - ez;
+    return (z < 0.02) ? omen_taylor(z) : 1.0 - ez;
 #else
     (void)ez;
     return -::expm1(-z);
@@ -949,8 +991,8 @@ struct PsoFn {
   double A, C, alpha;
   bool hot;  // dso == 0
   SPART_HD double operator()(double x) const {
-    if (hot) return Mx<double>::exp(A * x);  // A holds (K+k-sqrt(Kk)) LAI in this branch (:127)
-    return Mx<double>::exp(A * x + C * Mx<double>::one_minus_exp_neg(-alpha * x));  // :121-125 (x <= 0)
+    if (hot) return Mx<double>::exp_poly(A * x);  // A holds (K+k-sqrt(Kk)) LAI in this branch (:127)
+    return Mx<double>::exp_poly(A * x + C * Mx<double>::one_minus_exp_neg_poly(-alpha * x));  // :121-125 (x <= 0)
   }
 };
 

@@ -732,7 +732,8 @@ def test_lut_inversion_matches_brute_force(dtype, nb, torch_mod):
         if nb > 1:                                    # (one band: 20 000 rows 3e-5 apart, squared distances tie at the tolerance)
             assert np.mean(idx == true_idx) > 0.999
         assert np.max(np.abs(cost - true_cost)) < 10 * tol
-        assert list(idx[:5]) == [100, 101, 102, 103, 104] and np.all(cost[:5] == 0.0)    # exact members: the cost is recomputed from the row
+        if nb > 1 or dtype == "float64":              # exact members: the cost is recomputed from the row
+            assert list(idx[:5]) == [100, 101, 102, 103, 104] and np.all(cost[:5] == 0.0)
 
 
 def test_lut_inversion_small_and_tied(torch_mod):
