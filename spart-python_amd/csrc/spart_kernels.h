@@ -148,8 +148,11 @@ template <typename T, typename C> __device__ __forceinline__ CanopyPar<T> load_c
 // the "saddr" form of global_store.  Keeping the per-array bases in SGPRs (instead of one 64-bit per-lane pointer
 // per output array, 22 VGPRs for 11 arrays) is what lets the materialising kernel run at the occupancy of the
 // columns-only one.
+// Spectrum rows are written once and never read back by the kernel that writes them: non-temporal stores (the `nt` bit)
+// keep them from displacing the constants / tables in the caches.  Interleaved A/B on one box (tools/mat_ab.py,
+// tools/prospect_bench.py): materialised band kernel 3.15 -> 3.05 ms, k_prospect<double> 10k 0.182 -> 0.177 ms.
 #ifndef SPART_NT_STORES
-#define SPART_NT_STORES 0
+#define SPART_NT_STORES 1
 #endif
 template <typename T> __device__ __forceinline__ void store_row(T* row, unsigned byte_off, T v) {
 #if SPART_NT_STORES

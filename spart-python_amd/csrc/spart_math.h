@@ -208,6 +208,14 @@ __device__ __forceinline__ void stage_f64_tables() {}     // (host pass of hipcc
 #endif
 
 template <> struct Mx<double> {
+  // p x + c with a CONSTANT c (device: SGPR addend of a three-address v_fma_f64, see spart_horner)
+  static SPART_HD double horner_c(double p, double x, double c) {
+#if defined(__HIPCC__)
+    return spart_horner(p, x, c);
+#else
+    return p * x + c;
+#endif
+  }
 #if defined(__HIP_DEVICE_COMPILE__) && defined(SPART_FAST_MATH)
   static SPART_HD double exp_poly(double x) {
     // 2^k * e^r with k = rint(x / ln 2), |r| <= ln 2 / 2: Taylor to r^13 (r^14/14! < 4e-18)
@@ -226,7 +234,7 @@ template <> struct Mx<double> {
   static SPART_HD double exp_finish(double k, double r) {
     const int ki = (int)k;                                 // (NaN -> 0: r is NaN then, and so is the result)
     const double t = s_f64_exp_tab[ki & (F64_EXP_TAB - 1)];
-    double p = __builtin_fma(r, 1.0 / 24.0, 1.0 / 6.0);
+    double p = spart_horner(1.0 / 24.0, r, 1.0 / 6.0);      // (three-address FMA, constant addend from an SGPR pair: no copies)
     p = __builtin_fma(p, r, 0.5);
     p = __builtin_fma(p, r * r, r);                        // e^r - 1
     return __builtin_ldexp(__builtin_fma(t, p, t), ki >> 8);
@@ -251,9 +259,9 @@ template <> struct Mx<double> {
     const double m = __longlong_as_double((long long)((u & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull));   // [1, 2)
     const double R = s_f64_log_tab[2 * i], L = s_f64_log_tab[2 * i + 1];  // one ds_read_b128
     const double z = __builtin_fma(m, R, -1.0) + x * 0.0;   // (x * 0: a NaN / inf argument gives NaN instead of a finite value)
-    double q = __builtin_fma(z, -1.0 / 6.0, 0.2);
-    q = __builtin_fma(q, z, -0.25);
-    q = __builtin_fma(q, z, 1.0 / 3.0);
+    double q = spart_horner(-1.0 / 6.0, z, 0.2);
+    q = spart_horner(q, z, -0.25);
+    q = spart_horner(q, z, 1.0 / 3.0);
     q = __builtin_fma(q, z, -0.5);
     const double p = __builtin_fma(z * z, q, z);           // log1p(z)
     return __builtin_fma((double)e, 0.6931471805599453, L + p);
@@ -295,12 +303,11 @@ template <> struct Mx<double> {
 #if defined(SPART_FAST_MATH)
     if (x < 0.1) {
       double s = x * rcp(2.0 + x), s2 = s * s;
-      double p = 1.0 / 13.0;
-      p = p * s2 + 1.0 / 11.0;
-      p = p * s2 + 1.0 / 9.0;
-      p = p * s2 + 1.0 / 7.0;
-      p = p * s2 + 0.2;
-      p = p * s2 + 1.0 / 3.0;
+      double p = horner_c(1.0 / 13.0, s2, 1.0 / 11.0);
+      p = horner_c(p, s2, 1.0 / 9.0);
+      p = horner_c(p, s2, 1.0 / 7.0);
+      p = horner_c(p, s2, 0.2);
+      p = horner_c(p, s2, 1.0 / 3.0);
       p = p * s2 + 1.0;
       return 2.0 * s * p;
     }
@@ -439,11 +446,13 @@ template <> struct E3c<double> {
 };
 
 #if defined(__HIPCC__)
-SPART_HD double horner_step(double p, double x, double c) { return spart_horner(p, x, c); }
+// horner_uniform(p, x, c) = p x + c where c MUST be wave-uniform (a constant): on the device the float64 overload passes it
+// through an SGPR operand (spart_horner) -- a lane-varying c would silently become lane 0's value.
+SPART_HD double horner_uniform(double p, double x, double c) { return spart_horner(p, x, c); }
 #else
-SPART_HD double horner_step(double p, double x, double c) { return p * x + c; }
+SPART_HD double horner_uniform(double p, double x, double c) { return p * x + c; }
 #endif
-SPART_HD float horner_step(float p, float x, float c) { return p * x + c; }
+SPART_HD float horner_uniform(float p, float x, float c) { return p * x + c; }
 
 template <typename T> SPART_HD void plate_tau(T K, T& tau, T& u) {
   using C = E3c<T>;
@@ -457,7 +466,7 @@ template <typename T> SPART_HD void plate_tau(T K, T& tau, T& u) {
     const auto cg = C::gt();
     T g = cg[C::GD];
 #pragma unroll
-    for (int i = C::GD - 1; i >= 0; --i) g = horner_step(g, x, cg[i]);
+    for (int i = C::GD - 1; i >= 0; --i) g = horner_uniform(g, x, cg[i]);
     v = x * (g + x * Mx<T>::log(x));
   } else {
     // P(t)/Q(t) with t = 1/x, written in x (coefficients reversed) so that a single reciprocal is needed:
@@ -466,8 +475,8 @@ template <typename T> SPART_HD void plate_tau(T K, T& tau, T& u) {
     T pn = C::PSCALE * cp[0], qn = cq[0];  // (the factor 2 is folded into P's constants: exact)
 #pragma unroll
     for (int i = 1; i <= C::WD; ++i) {
-      pn = horner_step(pn, x, C::PSCALE * cp[i]);
-      qn = horner_step(qn, x, cq[i]);
+      pn = horner_uniform(pn, x, C::PSCALE * cp[i]);
+      qn = horner_uniform(qn, x, cq[i]);
     }
     v = Mx<T>::exp(-x) * pn * Mx<T>::rcp((x + T(3)) * qn);
   }
