@@ -130,7 +130,8 @@ def roofline(dtype, B, nb, stage_ms, step_ms, band_kernel):
     c, source, fresh = counters(dtype)
     if c is not None and B == c.get("batch") and nb == c.get("nb"):
         k = c["kernels"]
-        bk = next((v for n, v in k.items() if n.replace(" ", "") == band_kernel.replace(" ", "")), None)
+        key = band_kernel.replace(" ", "").rstrip(">")          # (round-2 profiles carry a fourth template argument)
+        bk = next((v for n, v in k.items() if n.replace(" ", "").startswith(key)), None)
         if bk and "SQ_INSTS_VALU" in bk:
             r["issue"] = {"valu_wave_insts_per_launch": bk["SQ_INSTS_VALU"],
                           "transcendental_wave_insts": bk.get("SQ_INSTS_VALU_TRANS_F32"),
@@ -146,12 +147,13 @@ def roofline(dtype, B, nb, stage_ms, step_ms, band_kernel):
     return r
 
 
-def stage_view(stage_ms, dtype, f32_bands=False):
-    """Per-stage HIP-event times as the bench line shows them.  In the default float32 mode the float64 slot pass and the
-    sensor kernel run on the context's side stream BESIDE the full-band kernel (spart_capi.hip: fork / join), so their
-    events measure when they finished relative to the end of the prelude, not how long they would take alone: they are
-    shown as one entry, `columns_beside_bands`, and the step is prelude + max(bands, columns_beside_bands)."""
-    if (dtype == "float32" or f32_bands) and os.environ.get("SPART_SIDE_STREAM", "1") != "0":
+def stage_view(stage_ms, dtype, f32_bands=False, pruned=False):
+    """Per-stage HIP-event times as the bench line shows them.  Whenever the full-band kernel runs (every mode but
+    prune_unused_bands), the slot pass and the sensor kernel run on the context's side stream BESIDE it (spart_capi.hip:
+    fork / join), so their events measure when they finished relative to the end of the prelude, not how long they would
+    take alone: they are shown as one entry, `columns_beside_bands`, and the step is prelude + max(bands,
+    columns_beside_bands)."""
+    if not pruned and os.environ.get("SPART_SIDE_STREAM", "1") != "0":
         return {"prelude": stage_ms["prelude"], "bands": stage_ms["bands"],
                 "columns_beside_bands": stage_ms["slots"] + stage_ms["sensor"]}
     return dict(stage_ms)
@@ -206,7 +208,7 @@ def run_config(torch, eng, P, dtype, steps, warmup, graph=False, **kw):
     eng.profile(0)
     ok = all(bool(torch.isfinite(v).all().item()) for v in out.values())
     return {"value": B / sec, "unit": "spectra/s", "ms_per_step": sec * 1e3, "batch": B, "steps": steps,
-            "stage_ms": stage_view({k: v / max(n, 1) for k, v in st.items()}, dtype, bool(kw.get("f32_bands"))), "finite": ok,
+            "stage_ms": stage_view({k: v / max(n, 1) for k, v in st.items()}, dtype, bool(kw.get("f32_bands")), bool(kw.get("prune"))), "finite": ok,
             "hip_graph": bool(graph)}
 
 
@@ -217,7 +219,7 @@ def extras(torch, args, dev):
     eng = get_engine(args.sensor, dev.index)
     P = torch.as_tensor(workloads.lhs_params(args.batch, "full").T.copy(), device=dev)
     r = run_config(torch, eng, P, "float64", steps, 1)
-    r["roofline"] = roofline("float64", args.batch, eng.nb, r["stage_ms"], r["ms_per_step"], "k_bands<double, 0, 1, true>")
+    r["roofline"] = roofline("float64", args.batch, eng.nb, r["stage_ms"], r["ms_per_step"], "k_bands<double, 0, 1>")
     r["dtype"] = "f64"
     # float64 columns over a float32 full-band pass (spart_materialize.f32_bands): the SAME float64 columns -- checked
     # here bit for bit -- at the float32 mode's speed; the 2162 bands of every sample are still all evaluated, in float32
@@ -311,7 +313,7 @@ def mode_records(torch, args, dev):
         "bytes_per_spectrum": MAT_BYTES_F32 + algorithmic_bytes(eng.nb, "float32"),
         "step_GBps": (nbytes + algorithmic_bytes(eng.nb, "float32") * B) / sec / 1e9,
         "finite": all(bool(torch.isfinite(out[k]).all().item()) for k in MAT_FIELDS),
-        "roofline": {"bound": "hbm", "kernel": "k_bands<float, 1, 1, true>", "kernel_ms": kms,
+        "roofline": {"bound": "hbm", "kernel": "k_bands<float, 1, 1>", "kernel_ms": kms,
                      "achieved": nbytes / (kms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": nbytes / (kms / 1e3) / 1e9 / HBM_PEAK_GBS, "frac_over_step": nbytes / sec / 1e9 / HBM_PEAK_GBS,
                      "algorithmic_bytes_per_launch": nbytes, "traffic": traffic,
@@ -363,11 +365,11 @@ def mode_records(torch, args, dev):
     torch.cuda.empty_cache()
     # --- LUT generation end to end: host parameter table in, host columns out (PCIe-inclusive; never the headline)
     P8 = np.tile(P1m, (8, 1))
-    spart_amd.generate_lut(P8[:1 << 20], args.sensor, chunk=1 << 20)
+    spart_amd.generate_lut(P8[:1 << 20], args.sensor, chunk=1 << 20, prune=False)
     best, bestp = 1e9, 1e9
     for _ in range(2):
         t0 = time.perf_counter()
-        o = spart_amd.generate_lut(P8, args.sensor, chunk=1 << 20)
+        o = spart_amd.generate_lut(P8, args.sensor, chunk=1 << 20, prune=False)
         best = min(best, time.perf_counter() - t0)
         del o
         t0 = time.perf_counter()
@@ -376,7 +378,8 @@ def mode_records(torch, args, dev):
         del o
     rec["lut_generate"] = {
         "workload": f"spart_amd.generate_lut: {P8.shape[0]} spectra (the 1M config-4 table x 8), {args.sensor}, fp32, pageable host table in -> "
-                    "host columns out, chunks of 1M, copies overlapped with the kernels; best of 2",
+                    "host columns out, chunks of 1M, copies overlapped with the kernels, all 2162 bands of every spectrum evaluated (prune=False; "
+                    "the function's default is the pruned path = pruned_value); best of 2",
         "value": P8.shape[0] / best, "unit": "spectra/s", "ms_per_step": best * 1e3,
         "host_bytes_per_spectrum": 27 * 8 + 3 * eng.nb * 4, "host_GBps": (27 * 8 + 3 * eng.nb * 4) * P8.shape[0] / best / 1e9,
         "pruned_value": P8.shape[0] / bestp, "pruned_ms": bestp * 1e3,
@@ -499,7 +502,7 @@ def main():
             ok = ok and all(bool(torch.isfinite(g).all().item()) for gl in gather_lists for g in gl)
         value = Bg * args.steps / dt
         stage_ms = {k: v / max(ncalls, 1) for k, v in stage.items()}
-        band_kernel = "k_bands<float, 0, 1, true>" if args.dtype == "float32" else "k_bands<double, 0, 1, true>"
+        band_kernel = "k_bands<float, 0, 1>" if args.dtype == "float32" else "k_bands<double, 0, 1>"
         line = {
             "metric": METRIC,
             "value": value, "unit": "spectra/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

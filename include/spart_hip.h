@@ -86,21 +86,22 @@ typedef struct spart_materialize {
   const void *rdry_in;         /* INPUT, optional: (B,2001) user dry-soil spectra in `dtype` (SoilParametersFromFile,
                                   bsm.py:42-43, 155-199); params[9..11] (B, lat, lon) may then be NULL */
   void *band_mean;             /* (4,2162) batch means of rso, rdo, rsd, rdd (LUT summary; no reference counterpart) */
-  int32_t prune_unused_bands;  /* 0 (default): every one of the 2162 bands of every sample is evaluated and
-                                  feeds band_mean's per-chunk sums; 1: bands that no requested output needs
-                                  may be skipped (columns are identical, the work is not "full spectra") */
-  int32_t f32_columns;         /* dtype SPART_F32 only.  0 (default): the <= 2 nb spectral bands the sensor columns
-                                  depend on (np.interp support points, SPART.py:220-223) are evaluated in float64 on
-                                  top of the float32 full-band pass, so R_TOC / R_TOA / L_TOA are the float64 mode's
-                                  values rounded once to float32 (the 1e-4 contract then also holds for nearly
+  int32_t prune_unused_bands;  /* R_TOC / R_TOA / L_TOA (and rsoil) ALWAYS come from the <= 2 nb spectral bands they depend on
+                                  (np.interp support points, SPART.py:220-223): prelude -> sensor-slot pass -> sensor kernel.
+                                  0 (default): beside that, every one of the 2162 bands of every sample is evaluated by the
+                                  fused full-band kernel (band sums / band_mean / the spectra requested above); 1: that
+                                  kernel only runs for requested spectra -- identical columns (the same kernels produce
+                                  them), the work is not "full spectra" */
+  int32_t f32_columns;         /* dtype SPART_F32 only.  0 (default): the column path (prelude constants, sensor-slot bands,
+                                  SMAC, TOC->TOA) is float64 whatever the dtype, so R_TOC / R_TOA / L_TOA are the float64
+                                  mode's values rounded once to float32 (the 1e-4 contract then also holds for nearly
                                   conservative PROSPECT-PRO leaves, where the reference's canopy formulas cancel,
-                                  sailh.py:185-214); materialised spectra and band_mean stay float32 arithmetic.
-                                  1: the columns are taken from the float32 band arithmetic itself */
+                                  sailh.py:185-214); materialised spectra and band_mean are float32 arithmetic.
+                                  1: the sensor-slot bands are evaluated in float32 as well (fast prelude) */
   int32_t f32_bands;           /* dtype SPART_F64 only.  1: R_TOC / R_TOA / L_TOA (and rsoil, La) are float64 and IDENTICAL
-                                  to the float64 mode's -- prelude, sensor-slot bands, SMAC and TOC->TOA in float64 --
-                                  while the evaluation of all 2162 bands of every sample (the band sums) runs in float32:
-                                  the reference's precision on the columns at the float32 mode's speed.  Materialised
-                                  spectra, band_mean and rdry_in cannot be combined with it (SPART_ERR_INVALID). */
+                                  to the float64 mode's -- they come from the same float64 column path -- while the
+                                  evaluation of all 2162 bands of every sample (the band sums) runs in float32.
+                                  Materialised spectra, band_mean and rdry_in cannot be combined with it (SPART_ERR_INVALID). */
 } spart_materialize;
 
 int spart_ctx_create(spart_ctx **out, int device, const spart_tables *tables);

@@ -24,9 +24,7 @@ struct spart_ctx {
   double* Ea = nullptr;     // (NWL)
   int nb = 0, nslot = 0;
   int pf = NWLS, po = NWL;  // row pitch (elements) of the 2162- / 2001-wide spectrum arrays (spart_ctx_set_row_pitch)
-  int* need_slot = nullptr;  // (2048) eval index -> slot or -1
-  int* no_slot = nullptr;    // (2048) all -1 (the full-band kernel of the default float32 mode stores no G rows)
-  int* slot_band = nullptr;  // (nslot) slot -> eval index (pruned mode)
+  int* slot_band = nullptr;  // (nslot) slot -> eval index (the bands the sensor-slot pass evaluates)
   int* slot0 = nullptr;      // (nb)
   int* slot1 = nullptr;      // (nb)
   double* frac = nullptr;    // (nb)
@@ -256,15 +254,16 @@ static int sailh_impl(spart_ctx* ctx, int64_t B, const void* rho, const void* ta
   return SPART_OK;
 }
 
-// T = dtype of the full-band kernel and of the outputs; TG = dtype of the prelude's constants, of the G rows at the
-// sensor slots and of the rsoil slots.  <double,double> = float64 mode; <float,double> = the default float32 mode
-// (sensor-slot bands re-evaluated in float64, k_bands_pruned); <float,float> = spart_materialize.f32_columns.
-// TO = dtype of the (B, nb) outputs: T, except for float64 columns over a float32 full-band pass (f32_bands).
+// T = dtype of the full-band kernel (band sums, materialised spectra); TG = dtype of the column path: the prelude's
+// constants, the sensor-slot pass, the G rows and rsoil slots (double, except spart_materialize.f32_columns); TO = dtype
+// of the (B, nb) outputs.  <double,double,double> = float64 mode; <float,double,float> = the default float32 mode;
+// <float,double,double> = f32_bands; <float,float,float> = f32_columns.
+// In EVERY mode the columns come from prelude -> k_slots<TG> -> k_sensor, i.e. from the <= 2 nb bands they depend on; the
+// full-band kernel runs beside that on the caller's stream whenever full spectra are asked for (opt = NULL: band sums).
 template <typename T, typename TG, typename TO = T>
 static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_NPARAM], const double* rho_th,
                     const double* tau_th, void* R_TOC, void* R_TOA, void* L_TOA, const spart_materialize* opt, char* wsp,
                     const Workspace& ws, hipStream_t st) {
-  constexpr bool HYBRID = sizeof(T) != sizeof(TG);
   ParamPtrs pp;
   for (int i = 0; i < NPARAM; ++i) pp.p[i] = params[i];
   pp.rho_th = rho_th;
@@ -277,25 +276,9 @@ static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_
   double* atm = (double*)(wsp + ws.atm_off);
   TG* G = (TG*)(wsp + ws.g_off);
   TG* gs = (TG*)(wsp + ws.gs_off);
-  int rc;
-  // optional per-stage timing: five events per call (before the prelude, after the prelude, the full-band kernel, the
-  // slot pass, the sensor kernel), recorded on the caller's stream
-  const bool prof = ctx->profile && ctx->ev_used + NEV <= ctx->ev.size();
-  hipEvent_t* ev = prof ? &ctx->ev[ctx->ev_used] : nullptr;
-  if (prof) HIP_TRY(ctx, hipEventRecord(ev[0], st));
-  {
-    Range r("SPART prelude (geometry, LIDF, hot spot, soil factors)");
-    // legacy float32 columns: the fast prelude; otherwise the literal one, so that the default float32 mode's
-    // columns are exactly the float64 mode's
-    rc = launch_prelude(ctx, sizeof(TG) == 4, pp, PRE_ALL, B, Bp, sizeof(T) == 4 ? cstF : nullptr,
-                        sizeof(TG) == 8 ? cstD : nullptr, atm, st);
-  }
-  if (rc) return rc;
-  Range rb("SPART bands + sensor (BSM, PROSPECT, SAILH | interp, SMAC, TOC->TOA)");
+  // ---- everything that can fail on its arguments is checked BEFORE any launch (and before the side stream is forked)
   int chunk = pick_chunk(B);
   int64_t nchunk = (B + chunk - 1) / chunk;
-  const T* tab = sizeof(T) == 4 ? (const T*)ctx->tabF : (const T*)ctx->tabD;
-  const TG* tabG = sizeof(TG) == 4 ? (const TG*)ctx->tabF : (const TG*)ctx->tabD;
   MatPtrs<T> mp;
   std::memset(&mp, 0, sizeof(mp));
   mp.pf = ctx->pf; mp.po = ctx->po;
@@ -305,88 +288,100 @@ static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_
     mp.leaf_refl = (T*)opt->leaf_refl; mp.leaf_tran = (T*)opt->leaf_tran; mp.leaf_kchl = (T*)opt->leaf_kchl;
     mp.soil_refl = (T*)opt->soil_refl; mp.soil_dry = (T*)opt->soil_refl_dry;
     mp.rso = (T*)opt->rso; mp.rdo = (T*)opt->rdo; mp.rsd = (T*)opt->rsd; mp.rdd = (T*)opt->rdd;
-    mp.gsoil = (want_rsoil && !HYBRID) ? (T*)gs : nullptr;      // hybrid: the rsoil slots come from the slot pass
     mp.rdry_in = (const T*)opt->rdry_in;
-    mat = mp.rdry_in || mp.leaf_refl || mp.leaf_tran || mp.leaf_kchl || mp.soil_refl || mp.soil_dry || mp.rso || mp.rdo || mp.rsd ||
-          mp.rdd || mp.gsoil;
+    mat = mp.leaf_refl || mp.leaf_tran || mp.leaf_kchl || mp.soil_refl || mp.soil_dry || mp.rso || mp.rdo || mp.rsd || mp.rdd;
   }
-  dim3 grid(xcd_grid(nchunk));
-  T* bsum = (T*)(wsp + ws.bs_off);
   if (mat && !chunk_fits_32bit(chunk, ctx->pf, sizeof(T)))
     return fail(ctx, SPART_ERR_INVALID, "batch too large for materialised spectra in one call (chunk %d rows x pitch %d)", chunk, ctx->pf);
   const bool full = !(opt && opt->prune_unused_bands);
   if (opt && opt->band_mean && !full)
     return fail(ctx, SPART_ERR_INVALID, "spart_run_batch: band_mean needs prune_unused_bands = 0");
-  if (prof) HIP_TRY(ctx, hipEventRecord(ev[1], st));
-  // hybrid: the full-band kernel stores no G rows (they come from the float64 slot pass below).  SPART_HYBRID_NOSLOTS
-  // selects the kernel variant compiled without the store code; by default the SAME kernel as the other modes runs
-  // with an all -1 slot map (the store is never reached): that schedule measured 1.4 % faster than the variant.
-  const int* need = HYBRID ? (const int*)ctx->no_slot : (const int*)ctx->need_slot;
-#ifdef SPART_HYBRID_NOSLOTS
-  constexpr bool SLOTS = !HYBRID;
-#else
-  constexpr bool SLOTS = true;
-#endif
-#define SPART_LAUNCH_BANDS(M, F)                                                                                 \
-  hipLaunchKernelGGL((k_bands<T, M, F, SLOTS>), grid, dim3(TILE), 0, st, tab, cst, Bp, need, ctx->nslot,         \
-                     (T*)(HYBRID ? nullptr : (void*)G), B, chunk, mp, bsum)
+  const int narr = 3 + (want_rsoil ? 1 : 0) + ((opt && opt->La) ? 1 : 0);
+  const size_t lds = (size_t)narr * 64 * ctx->nb * sizeof(TO);     // <= 5 * 64 * 64 * 8 = 160 KiB only for nb = 64 fp64
+  if (lds > 64 * 1024) return fail(ctx, SPART_ERR_INVALID, "spart_run_batch: %d sensor bands need %zu B of LDS staging", ctx->nb, lds);
+  int rc;
+  // optional per-stage timing: five events per call (before the prelude, after the prelude, the full-band kernel, the
+  // slot pass, the sensor kernel)
+  const bool prof = ctx->profile && ctx->ev_used + NEV <= ctx->ev.size();
+  hipEvent_t* ev = prof ? &ctx->ev[ctx->ev_used] : nullptr;
+  if (prof) HIP_TRY(ctx, hipEventRecord(ev[0], st));
   const bool four = opt && opt->band_mean;     // the four band sums are only kept apart when their means are asked for
   const bool bands = mat || full;              // the full-band kernel runs (otherwise: pruned, slot pass only)
-  const bool slots_done = !HYBRID && bands;    // (the non-hybrid band kernels write the G rows themselves)
-  // Default float32 mode: the sensor columns do not depend on the full-band kernel at all (slot pass -> sensor kernel),
-  // so those two float64 kernels run on the context's side stream BESIDE the float32 full-band kernel and fill issue
-  // slots it leaves idle; the caller's stream waits for them at the end.
-  const bool fork = HYBRID && bands && ctx->side != nullptr;
+  {
+    Range r("SPART prelude (geometry, LIDF, hot spot, soil factors)");
+    // legacy float32 columns (TG = float): the fast prelude; otherwise the literal one.  cstF only when a float32
+    // full-band kernel (or the float32 slot pass) will read it.
+    rc = launch_prelude(ctx, sizeof(TG) == 4, pp, PRE_ALL, B, Bp, (sizeof(TG) == 4 || (sizeof(T) == 4 && bands)) ? cstF : nullptr,
+                        sizeof(TG) == 8 ? cstD : nullptr, atm, st);
+  }
+  if (rc) return rc;
+  Range rb("SPART bands + sensor (BSM, PROSPECT, SAILH | interp, SMAC, TOC->TOA)");
+  const T* tab = sizeof(T) == 4 ? (const T*)ctx->tabF : (const T*)ctx->tabD;
+  const TG* tabG = sizeof(TG) == 4 ? (const TG*)ctx->tabF : (const TG*)ctx->tabD;
+  dim3 grid(xcd_grid(nchunk));
+  T* bsum = (T*)(wsp + ws.bs_off);
+  if (prof) HIP_TRY(ctx, hipEventRecord(ev[1], st));
+  // The columns do not depend on the full-band kernel, so the slot pass + sensor kernel run on the context's side stream
+  // BESIDE it and fill issue slots it leaves idle; the caller's stream waits for them at the end.
+  const bool fork = bands && ctx->side != nullptr;
   hipStream_t s2 = fork ? ctx->side : st;
-  auto columns = [&]() -> int {                // slot pass (where the G rows are not there yet) + sensor kernel, on s2
-    if (!slots_done) {
-      const int64_t nblk = (B + 255) / 256;                            // 256-sample blocks, dealt to the XCDs in groups of 8
-      hipLaunchKernelGGL((k_slots<TG, T>), dim3((unsigned)(((nblk + 7) / 8) * 8 * ctx->nslot)), dim3(256), 0, s2, tabG,
-                         cstG, Bp, (const int*)ctx->slot_band, G, (TG*)(want_rsoil ? gs : nullptr),
-                         (const T*)(opt ? opt->rdry_in : nullptr), ctx->po, B, ctx->nslot);
-      HIP_TRY(ctx, hipGetLastError());
-    }
+  auto columns = [&]() -> int {                // slot pass + sensor kernel, on s2
+    const int64_t nblk = (B + 255) / 256;                            // 256-sample blocks, dealt to the XCDs in groups of 8
+    hipLaunchKernelGGL((k_slots<TG, TO>), dim3((unsigned)(((nblk + 7) / 8) * 8 * ctx->nslot)), dim3(256), 0, s2, tabG,
+                       cstG, Bp, (const int*)ctx->slot_band, G, (TG*)(want_rsoil ? gs : nullptr),
+                       (const TO*)(opt ? opt->rdry_in : nullptr), ctx->po, B, ctx->nslot);
+    HIP_TRY(ctx, hipGetLastError());
     if (prof) HIP_TRY(ctx, hipEventRecord(ev[3], s2));
     SensorTab stb{ctx->slot0, ctx->slot1, ctx->frac, ctx->coef, ctx->econv, ctx->nb, ctx->nslot};
-    const int narr = 3 + (want_rsoil ? 1 : 0) + ((opt && opt->La) ? 1 : 0);
-    const size_t lds = (size_t)narr * 64 * ctx->nb * sizeof(TO);     // <= 5 * 64 * 64 * 8 = 160 KiB only for nb = 64 fp64
-    if (lds > 64 * 1024) return fail(ctx, SPART_ERR_INVALID, "spart_run_batch: %d sensor bands need %zu B of LDS staging", ctx->nb, lds);
     // 4 waves (each walking every 4th band) per 64-sample workgroup: with one wave per band (13 for Sentinel-2) a
     // CU holds a single workgroup and the kernel is 0.25 ms per 1M spectra slower (sweep 2..13: 2-4 equal)
     const int nwave = ctx->nb < 4 ? ctx->nb : 4;
-    const GLayout gl = slots_done ? GLayout{4, 1, (int64_t)ctx->nslot * 4, 1, (int64_t)ctx->nslot}     // written by k_bands
-                                  : GLayout{4 * Bp, Bp, 1, Bp, 1};                                       // written by k_slots
-    hipLaunchKernelGGL((k_sensor<TO, TG>), dim3((unsigned)((B + 63) / 64)), dim3(64 * nwave), lds, s2, stb, (const TG*)G, gl,
+    hipLaunchKernelGGL((k_sensor<TO, TG>), dim3((unsigned)((B + 63) / 64)), dim3(64 * nwave), lds, s2, stb, (const TG*)G,
                        (const double*)atm, Bp, B, (TO*)R_TOC, (TO*)R_TOA, (TO*)L_TOA, (const TG*)(want_rsoil ? gs : nullptr),
                        (TO*)(opt ? opt->rsoil : nullptr), (TO*)(opt ? opt->La : nullptr));
     HIP_TRY(ctx, hipGetLastError());
     if (prof) HIP_TRY(ctx, hipEventRecord(ev[4], s2));
     return SPART_OK;
   };
-  if (fork) {                                  // side stream first: its kernels are in the queue before the 65k workgroups of k_bands
+  auto band_kernels = [&]() -> int {           // the full-band kernel (+ the batch-mean reduction), on the caller's stream
+#define SPART_LAUNCH_BANDS(M, F) \
+  hipLaunchKernelGGL((k_bands<T, M, F>), grid, dim3(TILE), 0, st, tab, cst, Bp, B, chunk, mp, bsum)
+    if (mat && mp.rdry_in && full && four) SPART_LAUNCH_BANDS(2, 2);
+    else if (mat && mp.rdry_in && full) SPART_LAUNCH_BANDS(2, 1);
+    else if (mat && mp.rdry_in) SPART_LAUNCH_BANDS(2, 0);
+    else if (mat && full && four) SPART_LAUNCH_BANDS(1, 2);
+    else if (mat && full) SPART_LAUNCH_BANDS(1, 1);
+    else if (mat) SPART_LAUNCH_BANDS(1, 0);
+    else if (full && four) SPART_LAUNCH_BANDS(0, 2);
+    else if (full) SPART_LAUNCH_BANDS(0, 1);
+#undef SPART_LAUNCH_BANDS
+    HIP_TRY(ctx, hipGetLastError());
+    if (prof) HIP_TRY(ctx, hipEventRecord(ev[2], st));
+    if (opt && opt->band_mean) {
+      hipLaunchKernelGGL((k_bandmean<T>), dim3((4 * NWLS + 255) / 256), dim3(256), 0, st, (const T*)bsum, nchunk, B,
+                         (T*)opt->band_mean);
+      HIP_TRY(ctx, hipGetLastError());
+    }
+    return SPART_OK;
+  };
+  if (!bands) {                                // pruned: the column path alone
+    if (prof) HIP_TRY(ctx, hipEventRecord(ev[2], st));
+    rc = columns();
+  } else if (!fork) {
+    if ((rc = band_kernels()) == SPART_OK) rc = columns();
+  } else {                                     // side stream first: its kernels are queued before the 65k workgroups of k_bands
     HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
-    if ((rc = columns())) return rc;
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->side));
+    rc = columns();
+    const int rc2 = band_kernels();
+    // whatever happened after the fork, the caller's stream is ordered after the side stream's work again (and a HIP-graph
+    // capture in progress gets its join): an error code is returned only after the join has been recorded
+    const hipError_t ej = hipEventRecord(ctx->ev_join, ctx->side);
+    const hipError_t ew = ej == hipSuccess ? hipStreamWaitEvent(st, ctx->ev_join, 0) : ej;
+    if (rc == SPART_OK) rc = rc2;
+    if (rc == SPART_OK && ew != hipSuccess) rc = fail(ctx, SPART_ERR_HIP, "spart_run_batch: joining the side stream: %s", hipGetErrorString(ew));
   }
-  if (mat && mp.rdry_in && full && four) SPART_LAUNCH_BANDS(2, 2);
-  else if (mat && mp.rdry_in && full) SPART_LAUNCH_BANDS(2, 1);
-  else if (mat && mp.rdry_in) SPART_LAUNCH_BANDS(2, 0);
-  else if (mat && full && four) SPART_LAUNCH_BANDS(1, 2);
-  else if (mat && full) SPART_LAUNCH_BANDS(1, 1);
-  else if (mat) SPART_LAUNCH_BANDS(1, 0);
-  else if (full && four) SPART_LAUNCH_BANDS(0, 2);
-  else if (full) SPART_LAUNCH_BANDS(0, 1);
-#undef SPART_LAUNCH_BANDS
-  HIP_TRY(ctx, hipGetLastError());
-  if (prof) HIP_TRY(ctx, hipEventRecord(ev[2], st));
-  if (opt && opt->band_mean) {
-    hipLaunchKernelGGL((k_bandmean<T>), dim3((4 * NWLS + 255) / 256), dim3(256), 0, st, (const T*)bsum, nchunk, B,
-                       (T*)opt->band_mean);
-    HIP_TRY(ctx, hipGetLastError());
-  }
-  if (fork) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
-  else if ((rc = columns())) return rc;
+  if (rc) return rc;
   if (prof) {
     ctx->ev_forked.push_back(fork ? 1 : 0);
     ctx->ev_used += NEV;
@@ -512,8 +507,7 @@ int spart_ctx_econv(const spart_ctx* ctx, double* host_out) {
 int spart_ctx_destroy(spart_ctx* ctx) {
   if (!ctx) return SPART_OK;
   DeviceGuard g(ctx->device);
-  (void)hipFree(ctx->tabF); (void)hipFree(ctx->tabD); (void)hipFree(ctx->Ea); (void)hipFree(ctx->need_slot);
-  (void)hipFree(ctx->no_slot);
+  (void)hipFree(ctx->tabF); (void)hipFree(ctx->tabD); (void)hipFree(ctx->Ea);
   (void)hipFree(ctx->slot_band);
   (void)hipFree(ctx->slot0); (void)hipFree(ctx->slot1); (void)hipFree(ctx->frac); (void)hipFree(ctx->coef);
   (void)hipFree(ctx->econv);
@@ -629,9 +623,6 @@ int spart_ctx_create(spart_ctx** out, int device, const spart_tables* t) {
       spart_ctx_destroy(ctx);
       return SPART_ERR_HIP;
     }
-  }
-  if ((rc = upload(ctx, &ctx->need_slot, need)) || (rc = upload(ctx, &ctx->no_slot, std::vector<int>(NTILE * TILE, -1)))) {
-    std::snprintf(g_err, 512, "%s", ctx->err); spart_ctx_destroy(ctx); return rc;
   }
   {
     const char* e = std::getenv("SPART_SIDE_STREAM");            // "0" keeps every kernel on the caller's stream
@@ -810,10 +801,10 @@ int spart_run_batch(spart_ctx* ctx, int dtype, int64_t B, const double* const pa
       return fail(ctx, SPART_ERR_INVALID, "spart_run_batch: f32_bands goes with the sensor columns (and rsoil / La) only");
     return run_impl<float, double, double>(ctx, B, params, rho_thermal, tau_thermal, R_TOC, R_TOA, L_TOA, opt, wsp, ws, st);
   }
-  if (dtype == SPART_F64) return run_impl<double, double>(ctx, B, params, rho_thermal, tau_thermal, R_TOC, R_TOA, L_TOA, opt, wsp, ws, st);
+  if (dtype == SPART_F64) return run_impl<double, double, double>(ctx, B, params, rho_thermal, tau_thermal, R_TOC, R_TOA, L_TOA, opt, wsp, ws, st);
   return (opt && opt->f32_columns)
-             ? run_impl<float, float>(ctx, B, params, rho_thermal, tau_thermal, R_TOC, R_TOA, L_TOA, opt, wsp, ws, st)
-             : run_impl<float, double>(ctx, B, params, rho_thermal, tau_thermal, R_TOC, R_TOA, L_TOA, opt, wsp, ws, st);
+             ? run_impl<float, float, float>(ctx, B, params, rho_thermal, tau_thermal, R_TOC, R_TOA, L_TOA, opt, wsp, ws, st)
+             : run_impl<float, double, float>(ctx, B, params, rho_thermal, tau_thermal, R_TOC, R_TOA, L_TOA, opt, wsp, ws, st);
 }
 
 size_t spart_lut_workspace_bytes(int dtype, int64_t B, int nb, int64_t M) {

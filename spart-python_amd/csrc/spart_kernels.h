@@ -164,7 +164,6 @@ template <typename T> __device__ __forceinline__ void store_row(T* row, unsigned
 
 template <typename T> struct MatPtrs {
   T *leaf_refl, *leaf_tran, *leaf_kchl, *soil_refl, *soil_dry, *rso, *rdo, *rsd, *rdd;
-  T* gsoil;         // (B, nslot) wet soil at the sensor-band slots (debug column rsoil)
   const T* rdry_in; // optional (B, 2001) user dry-soil spectra (SoilParametersFromFile, bsm.py:42-43)
   int pf, po;       // row pitch (elements) of the 2162-wide / 2001-wide spectrum arrays (spart_ctx_set_row_pitch)
 };
@@ -172,14 +171,14 @@ template <typename T> struct MatPtrs {
 // ------------------------------------------------------------------------------------------
 // K2: the fused band kernel: PROSPECT + BSM + SAILH for every band of every sample.
 // grid.x = nchunk * NTILE (tile fastest), block = 256.
-// G receives rso, rdo, rsd, rdd at the bands the sensor needs: (B, nslot, 4).
 //
 // FULL >= 1 (the default mode of spart_run_batch): every one of the 2002 band evaluations of every sample is
 // observable -- each lane accumulates its band's canopy reflectances over the chunk and stores the sum: FULL = 1 one
 // value per lane (rso + rdo + rsd + rdd: bandsum[chunk][2048], 8 KB per chunk), FULL = 2 the four sums separately
 // (bandsum[chunk][2048][4], reduced to batch-mean spectra by k_bandmean; chosen when band_mean is requested).
-// Without that the compiler legally sinks most of the soil / canopy arithmetic into the `slot >= 0` store and skips
-// it for the waves that hold no sensor band; that behaviour is the explicit opt-in FULL = 0 ("prune_unused_bands").
+// Without an observable result per band the compiler is free to drop the arithmetic (an early version sank most of the
+// soil / canopy model under a conditional store and skipped it for 23 of 32 waves).  FULL = 0 exists only together with
+// MAT >= 1 (prune_unused_bands + materialised spectra: the stored spectra are the observable result).
 // MAT: 0 = sensor columns only; 1 = also store the requested full spectra; 2 = 1 + per-sample dry-soil spectra are
 // READ (rdry_in).  The read is its own variant because a global load inside the sample loop makes the compiler wait
 // for vmcnt(0) -- i.e. for every outstanding store of the previous sample -- once per sample, which serialises the
@@ -188,14 +187,13 @@ template <typename T> struct MatPtrs {
 // made the fp64 mode 24 % faster (50.7 -> 38.6 ms per 1M spectra); with the plate-model coefficients in constant
 // memory (spart_math.h, E3c<double>) three fit with 38 spilled values: 36.2 ms (with the coefficients as literals
 // three workgroups meant 96 spilled values and 104 ms).
-// need_slot: eval index -> sensor slot or -1.  In the default float32 mode the sensor columns do not come from this
-// kernel at all (SLOTS = false) but from k_slots<double> over the float64 constants.
-// SLOTS = false: this kernel stores no G rows (and no rsoil slots) at all.
-template <typename T, int MAT, int FULL, bool SLOTS>
+// The sensor columns never come from this kernel: in every mode R_TOC / R_TOA / L_TOA (and the debug rsoil column) are
+// produced by k_slots -> k_sensor from the <= 2 nb bands they depend on, so that they are the SAME numbers -- by
+// construction, not by compiler luck -- whether the full spectra are evaluated in float64, in float32, or not at all.
+template <typename T, int MAT, int FULL>
 __global__ __launch_bounds__(TILE, (sizeof(T) == 8 ? 3 : 1))
-void k_bands(const T* __restrict__ tab, const T* __restrict__ cst, int64_t Bp,
-                                                const int* __restrict__ need_slot, int nslot, T* __restrict__ G,
-                                                int64_t B, int chunk, MatPtrs<T> mat, T* __restrict__ bandsum) {
+void k_bands(const T* __restrict__ tab, const T* __restrict__ cst, int64_t Bp, int64_t B, int chunk, MatPtrs<T> mat,
+             T* __restrict__ bandsum) {
   int tile;
   int64_t ck;
   xcd_map(blockIdx.x, tile, ck);
@@ -206,7 +204,6 @@ void k_bands(const T* __restrict__ tab, const T* __restrict__ cst, int64_t Bp,
   const bool thermal = band == NWL;                    // the single thermal evaluation
   const int ti = band < NWL ? band : NWL - 1;          // thermal soil = soil at 2400 nm (SPART.py:440)
   const BandTab<T> tb = load_tab(tab, ti);
-  const int slot = (SLOTS && active) ? need_slot[band] : -1;
   const int64_t s0 = ck * chunk;
   const int64_t s1 = (s0 + chunk < B) ? s0 + chunk : B;
   T sum_so = T(0), sum_do = T(0), sum_sd = T(0), sum_dd = T(0);
@@ -291,17 +288,12 @@ void k_bands(const T* __restrict__ tab, const T* __restrict__ cst, int64_t Bp,
     } else if (FULL == 1) {
       sum_so += (rso + rdo) + (rsd + rdd);
     }
-    if (SLOTS && slot >= 0) {
-      T* g = G + (s * nslot + slot) * 4;                 // G[B][nslot][4] (k_sensor: GLayout)
-      g[0] = rso; g[1] = rdo; g[2] = rsd; g[3] = rdd;
-    }
     if (MAT) {
       if (active) {
         if (mat.rso) store_row(mat.rso, off_f, rso);
         if (mat.rdo) store_row(mat.rdo, off_f, rdo);
         if (mat.rsd) store_row(mat.rsd, off_f, rsd);
         if (mat.rdd) store_row(mat.rdd, off_f, rdd);
-        if (SLOTS && mat.gsoil && slot >= 0) (mat.gsoil + s * nslot)[slot] = rwet;
       }
       // thermal padding (SPART.py:427-470): the wave that holds the thermal evaluation (band 2001) copies it over
       // bands 2002..2161 of the padded spectra -- 160 values per array, three coalesced stores per lane
@@ -533,17 +525,11 @@ struct SensorTab {
 // j = w, w + nwave, ... so that the band index -- and with it the 48 SMAC coefficients, the interpolation
 // slots and the "is this gas absent in this band" tests -- is wave-uniform (scalar loads, scalar branches).
 // Results are staged in LDS and written out as whole (64 x nb) row blocks, coalesced.
-// Element strides of the G rows, G[slot * slot + q * comp + s * sample] (q = rso, rdo, rsd, rdd), and of the rsoil
-// slots gsoil[slot * gs_slot + s * gs_sample]: k_bands (band on lanes) writes them sample-major, (B, nslot, 4) and
-// (B, nslot); k_slots (sample on lanes) writes structure-of-arrays, [nslot][4][Bp] and [nslot][Bp].
-struct GLayout {
-  int64_t slot, comp, sample, gs_slot, gs_sample;
-};
-
+// G rows and rsoil slots are structure-of-arrays as k_slots (sample on lanes) writes them: G[slot][4][Bp], gsoil[slot][Bp].
 // TG: element type of the G rows / gsoil values (double in the default float32 mode, see k_slots).  atm is
 // structure-of-arrays with pitch Bp.
 template <typename T, typename TG>
-__global__ __launch_bounds__(1024) void k_sensor(SensorTab st, const TG* __restrict__ G, GLayout gl,
+__global__ __launch_bounds__(1024) void k_sensor(SensorTab st, const TG* __restrict__ G,
                                                  const double* __restrict__ atm, int64_t Bp, int64_t B, T* __restrict__ R_TOC, T* __restrict__ R_TOA,
                                                  T* __restrict__ L_TOA, const TG* __restrict__ gsoil,
                                                  T* __restrict__ o_rsoil, T* __restrict__ o_La) {
@@ -564,12 +550,12 @@ __global__ __launch_bounds__(1024) void k_sensor(SensorTab st, const TG* __restr
   for (int j = wave; j < nb; j += nwave) {
     const int sl0 = st.slot0[j], sl1 = st.slot1[j];
     const double f = st.frac[j];
-    const TG* g0 = G + sl0 * gl.slot + sc * gl.sample;
-    const TG* g1 = G + sl1 * gl.slot + sc * gl.sample;
+    const TG* g0 = G + (int64_t)sl0 * 4 * Bp + sc;
+    const TG* g1 = G + (int64_t)sl1 * 4 * Bp + sc;
     double v[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      double y0 = (double)g0[q * gl.comp], y1 = (double)g1[q * gl.comp];
+      double y0 = (double)g0[q * Bp], y1 = (double)g1[q * Bp];
       v[q] = y0 + (y1 - y0) * f;                     // np.interp (SPART.py:220-223)
     }
     SmacOut so = smac_band(a, st.coef + j, nb);
@@ -582,7 +568,7 @@ __global__ __launch_bounds__(1024) void k_sensor(SensorTab st, const TG* __restr
     stage[2 * tile + o] = (T)ltoa;
     int na = 3;
     if (o_rsoil && gsoil) {
-      double y0 = (double)gsoil[sl0 * gl.gs_slot + sc * gl.gs_sample], y1 = (double)gsoil[sl1 * gl.gs_slot + sc * gl.gs_sample];
+      double y0 = (double)gsoil[(int64_t)sl0 * Bp + sc], y1 = (double)gsoil[(int64_t)sl1 * Bp + sc];
       stage[na * tile + o] = (T)(y0 + (y1 - y0) * f);
       ++na;
     }

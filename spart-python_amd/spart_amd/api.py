@@ -473,9 +473,18 @@ class SPART:
         return (self.leafbio.columns() + self.soilpar.columns() + self.canopy.columns() + self.angles.columns()
                 + self.atm.columns() + [self.DOY])
 
+    _LAZY = ("atmopt", "leafopt", "soilopt", "canopyopt")
+
     def run(self, debug=False, materialize=False):
         """Returns the reference's DataFrame (columns Band, L_TOA, R_TOA, R_TOC indexed by band
-        centre) for scalar parameters, a BatchResult of (B, nb) arrays otherwise."""
+        centre) for scalar parameters, a BatchResult of (B, nb) arrays otherwise.
+
+        ONE spart_run_batch call.  The sensor columns depend on <= 2 nb of the 2162 bands, so a columns-only run
+        evaluates just those (spart_materialize.prune_unused_bands: bit-identical columns).  The attributes the reference
+        object carries after run() (SPART.py:66-81, 197, 209, 214, 229) -- ``atmopt`` and the full-spectrum
+        ``leafopt / soilopt / canopyopt`` -- are computed on FIRST ACCESS from the parameters of this run (one
+        spart_smac_batch, resp. one materialising spart_run_batch, cached); ``materialize=True`` computes the spectra
+        eagerly in the same call instead."""
         import pandas as pd
         _pro_warning(self.leafbio)
         eng = _engine.get_engine(self.sensor, self.device)
@@ -484,28 +493,24 @@ class SPART:
         if debug:
             fields.append("rsoil")
         if materialize:
-            fields += ["leaf_refl", "leaf_tran", "leaf_kchl", "soil_refl", "soil_refl_dry", "rso", "rdo", "rsd", "rdd"]
+            fields += _SPECTRA
         rdry = self.soilpar.rdry if getattr(self.soilpar, "rdry_set", False) else None
-        # float64 columns without full spectra: the 2162-band evaluation itself may run in float32 -- the columns (and
-        # rsoil, La) are bit-identical to the all-float64 evaluation (spart_materialize.f32_bands), 2.6x faster
-        f32_bands = self.dtype in ("float64", "fp64", "f64") and not materialize and rdry is None
-        res = eng.run(cols, self.dtype, rho_thermal=self.leafbio.rho_thermal, tau_thermal=self.leafbio.tau_thermal,
-                      materialize=fields, rdry=rdry, f32_bands=f32_bands)
+        th = (self.leafbio.rho_thermal, self.leafbio.tau_thermal)
+        res = eng.run(cols, self.dtype, rho_thermal=th[0], tau_thermal=th[1], materialize=fields, rdry=rdry,
+                      prune=not materialize)
         out = {k: _np(v) for k, v in res.items()}
         scalar = _is_scalar(*[c for c in cols if c is not None]) and out["R_TOC"].shape[0] == 1
         wl = self.sensorinfo["wl_smac"].T[0]
         bands = self.sensorinfo["band_id_smac"]
         # attributes documented at SPART.py:66-81
         self.R_TOC, self.R_TOA, self.L_TOA, self._La = out["R_TOC"], out["R_TOA"], out["L_TOA"], out["La"]
-        # atmopt (SPART.py:226-232): the nine SMAC fields, (1, nb) each for scalar inputs (smac.py:209-211), (B, nb) otherwise
-        sm = eng.smac(self.angles.columns(), self.atm.columns())
-        self.atmopt = AtmosphericOptics(*[_np(sm[f]) for f in _engine.SMAC_FIELDS])
+        # what the lazy attributes are evaluated from: the parameters of THIS run (the objects may be modified afterwards)
+        self.__dict__["_last"] = dict(eng=eng, cols=cols, th=th, rdry=rdry, scalar=scalar,
+                                      angles=self.angles.columns(), atm=self.atm.columns())
+        for k in self._LAZY:
+            self.__dict__.pop(k, None)
         if materialize:
-            sc = scalar
-            col = (lambda a: a[0][:, None].copy()) if sc else (lambda a: a)
-            self.leafopt = LeafOptics(col(out["leaf_refl"]), col(out["leaf_tran"]), col(out["leaf_kchl"]))
-            self.soilopt = SoilOptics(col(out["soil_refl"]), col(out["soil_refl_dry"]))
-            self.canopyopt = CanopyReflectances(*[col(out[k]) for k in ("rso", "rdo", "rsd", "rdd")])
+            self._set_spectra(out, scalar)
         if not scalar:
             return BatchResult(out, wl, bands)
         table = pd.DataFrame(zip(bands, out["L_TOA"][0], out["R_TOA"][0], out["R_TOC"][0]), index=wl,
@@ -513,3 +518,30 @@ class SPART:
         if debug:
             table["rsoil"] = out["rsoil"][0]                                    # SPART.py:262-267
         return table
+
+    def _set_spectra(self, out, scalar):
+        col = (lambda a: a[0][:, None].copy()) if scalar else (lambda a: a)
+        self.__dict__["leafopt"] = LeafOptics(col(out["leaf_refl"]), col(out["leaf_tran"]), col(out["leaf_kchl"]))
+        self.__dict__["soilopt"] = SoilOptics(col(out["soil_refl"]), col(out["soil_refl_dry"]))
+        self.__dict__["canopyopt"] = CanopyReflectances(*[col(out[k]) for k in ("rso", "rdo", "rsd", "rdd")])
+
+    def __getattr__(self, name):
+        # only reached when ``name`` is not set: the reference's post-run attributes, computed on first access
+        if name in SPART._LAZY:
+            last = self.__dict__.get("_last")
+            if last is None:
+                raise AttributeError(f"{name} is set by run() (SPART.py:197-229)")
+            eng = last["eng"]
+            if name == "atmopt":
+                # atmopt (SPART.py:226-232): the nine SMAC fields, (1, nb) each for scalar inputs (smac.py:209-211), (B, nb) otherwise
+                sm = eng.smac(last["angles"], last["atm"])
+                self.__dict__["atmopt"] = AtmosphericOptics(*[_np(sm[f]) for f in _engine.SMAC_FIELDS])
+            else:
+                res = eng.run(last["cols"], self.dtype, rho_thermal=last["th"][0], tau_thermal=last["th"][1],
+                              materialize=_SPECTRA, rdry=last["rdry"])
+                self._set_spectra({k: _np(res[k]) for k in _SPECTRA}, last["scalar"])
+            return self.__dict__[name]
+        raise AttributeError(f"{type(self).__name__!r} object has no attribute {name!r}")
+
+
+_SPECTRA = ["leaf_refl", "leaf_tran", "leaf_kchl", "soil_refl", "soil_refl_dry", "rso", "rdo", "rsd", "rdd"]

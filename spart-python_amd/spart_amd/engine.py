@@ -1,6 +1,7 @@
 """Host-side driver of the HIP kernels: one Engine = one libspart_hip context = one
 (device, sensor) pair.  torch tensors are used for device memory and streams only; every
 compute call goes through the C ABI (include/spart_hip.h)."""
+import collections
 import ctypes
 
 import numpy as np
@@ -68,6 +69,7 @@ class Engine:
         _lib.check(self.lib, None, rc)
         self.ctx = ctx
         self._ws_buf = None
+        self.calls = collections.Counter()        # C-ABI compute calls issued through this engine, by entry point
         self.row_pitch = {_lib.NWLS: _lib.NWLS, _lib.NWL: _lib.NWL}
         if row_pitch is not None:
             pf, po = int(row_pitch[0]), int(row_pitch[1])
@@ -157,6 +159,7 @@ class Engine:
         td = self._tdtype(dt)
         out = [self._alloc_spec(B, _lib.NWL, td) if n in outputs else None for n in ("refl", "tran", "kChlrel")]
         ws, wsn = self._workspace(dt, B)
+        self.calls["spart_prospect_batch"] += 1
         rc = self.lib.spart_prospect_batch(self.ctx, dt, B, self._ptrs(cols), *[o.data_ptr() if o is not None else None for o in out],
                                            ws, wsn, self._stream())
         _lib.check(self.lib, self.ctx, rc)
@@ -178,6 +181,7 @@ class Engine:
         td = self._tdtype(dt)
         out = [self._alloc_spec(B, _lib.NWL, td) for _ in range(2)]
         ws, wsn = self._workspace(dt, B)
+        self.calls["spart_bsm_batch"] += 1
         rc = self.lib.spart_bsm_batch(self.ctx, dt, B, self._ptrs(cols), rd.data_ptr() if rd is not None else None,
                                       out[0].data_ptr(), out[1].data_ptr(), ws, wsn, self._stream())
         _lib.check(self.lib, self.ctx, rc)
@@ -186,6 +190,7 @@ class Engine:
     def lidf(self, LIDFa, LIDFb):
         cols, B = self.columns([LIDFa, LIDFb])
         out = self.torch.empty((B, _lib.NLINCL), dtype=self.torch.float64, device=self.device)
+        self.calls["spart_lidf_batch"] += 1
         rc = self.lib.spart_lidf_batch(self.ctx, B, cols[0].data_ptr(), cols[1].data_ptr(), out.data_ptr(),
                                        self._stream())
         _lib.check(self.lib, self.ctx, rc)
@@ -203,6 +208,7 @@ class Engine:
         td = self._tdtype(dt)
         out = [self._alloc_spec(B, _lib.NWLS, td) for _ in range(4)]
         ws, wsn = self._workspace(dt, B)
+        self.calls["spart_sailh_batch"] += 1
         rc = self.lib.spart_sailh_batch(self.ctx, dt, B, rho.data_ptr(), tau.data_ptr(), rs.data_ptr(),
                                         self._ptrs(cols[:4]), self._ptrs(cols[4:]), self._ptrs(out), ws, wsn,
                                         self._stream())
@@ -214,6 +220,7 @@ class Engine:
         cols, B = self.columns(list(angles3) + list(atm4))
         out = [self.torch.empty((B, self.nb), dtype=self.torch.float64, device=self.device) for _ in range(9)]
         ws, wsn = self._workspace(_lib.SPART_F64, B)
+        self.calls["spart_smac_batch"] += 1
         rc = self.lib.spart_smac_batch(self.ctx, B, self._ptrs(cols[:3]), self._ptrs(cols[3:]), self._ptrs(out), ws, wsn,
                                        self._stream())
         _lib.check(self.lib, self.ctx, rc)
@@ -293,6 +300,7 @@ class Engine:
             ws, wsn = ctypes.c_void_p(_workspace.data_ptr()), ctypes.c_size_t(_workspace.numel())
         else:
             ws, wsn = self._workspace(dt, B)
+        self.calls["spart_run_batch"] += 1
         rc = self.lib.spart_run_batch(self.ctx, dt, B, self._ptrs(cols), th[0].data_ptr() if th[0] is not None else None,
                                       th[1].data_ptr() if th[1] is not None else None, res["R_TOC"].data_ptr(),
                                       res["R_TOA"].data_ptr(), res["L_TOA"].data_ptr(),
@@ -359,6 +367,7 @@ class Engine:
         cost = torch.empty((M,), dtype=td, device=self.device)
         n = int(self.lib.spart_lut_workspace_bytes(dt, B, nb, M))
         ws = torch.empty(max(n, 256), dtype=torch.uint8, device=self.device)
+        self.calls["spart_lut_nearest"] += 1
         rc = self.lib.spart_lut_nearest(self.ctx, dt, B, nb, lut.data_ptr(), M, obs.data_ptr(),
                                         w.data_ptr() if w is not None else None, idx.data_ptr(), cost.data_ptr(),
                                         ws.data_ptr(), ctypes.c_size_t(ws.numel()), self._stream())

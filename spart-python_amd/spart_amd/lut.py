@@ -41,10 +41,11 @@ def _prefault(a):
     return _libc.madvise(lo, a.ctypes.data + a.nbytes - lo, _MADV_POPULATE_WRITE) == 0
 
 
-def generate_lut(params, sensor, path=None, dtype="float32", chunk=1 << 20, device=None, prune=False, fault_threads=8,
+def generate_lut(params, sensor, path=None, dtype="float32", chunk=1 << 20, device=None, prune=True, fault_threads=8,
                  f32_bands=False):
     """params: (B, 27) array-like on the HOST (numpy / memmap).  Returns dict of host arrays (np.memmap when
-    ``path`` is given).  ``prune=True`` evaluates only the bands the sensor needs (identical columns);
+    ``path`` is given).  ``prune=True`` (default: a LUT holds the sensor columns only) evaluates just the <= 2 nb bands those columns
+    depend on -- bit-identical columns; ``prune=False`` also evaluates the other bands of every spectrum (band sums);
     ``dtype="float64", f32_bands=True`` gives float64 columns identical to the float64 mode's at the float32 mode's speed.
 
     Pipeline per chunk i (three HIP streams; the host never holds a private staging copy):

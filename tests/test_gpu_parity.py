@@ -324,7 +324,7 @@ def test_float32_tolerance_at_size(kind, sensor, torch_mod):
 
 def test_float32_columns_are_the_float64_columns_rounded(golden, torch_mod):
     """The default float32 mode takes its sensor columns from a float64 evaluation of the sensor-slot bands over the
-    float64 prelude (k_bands_pruned<double>): on every sensor (integer and fractional band centres), with debug rsoil
+    float64 prelude (k_slots<double>): on every sensor (integer and fractional band centres), with debug rsoil
     and with user dry-soil spectra, they equal the float64 mode's columns converted to float32."""
     from spart_amd import get_engine, workloads
     for sensor, kind in (("Sentinel2A-MSI", "full"), ("Sentinel2B-MSI", "pro"), ("TerraAqua-MODIS", "full"),
@@ -386,11 +386,34 @@ def test_reference_style_api(golden, torch_mod, capsys):
     df2 = SPART.SPART(SPART.SoilParameters(0.5, 0, 100, 20, 25, 0.015), pro, canopy,
                       SPART.AtmosphericProperties(0.325, 0.35, 1.41), angles, "Sentinel2B-MSI", 100).run()
     assert "PROSPECT-PRO was called" in capsys.readouterr().out
-    # atmopt (SPART.py:66-81, 226-232; smac.py:209-211) is set by every run(): golden SMAC row 0 = these defaults
+    # atmopt (SPART.py:66-81, 226-232; smac.py:209-211) belongs to every run(): golden SMAC row 0 = these defaults
     gs = golden["smac"]
     sp = SPART.SPART(SPART.SoilParameters(0.5, 0, 100, 20, 25, 0.015), SPART.LeafBiology(40, 0.01, 0.02, 0, 10, 10, 1.5), canopy,
                      SPART.AtmosphericProperties(0.325, 0.35, 1.41), angles, "Sentinel2A-MSI", 100)
+    from spart_amd import get_engine
+    eng = get_engine("Sentinel2A-MSI", None)
+    assert not hasattr(sp, "atmopt") and not hasattr(sp, "canopyopt")              # set by run() only (SPART.py:197-229)
+    before = dict(eng.calls)
     sp.run()
+    # ONE library call per run(); the reference object's atmopt / leafopt / soilopt / canopyopt are evaluated on first access
+    assert eng.calls["spart_run_batch"] == before.get("spart_run_batch", 0) + 1
+    assert eng.calls["spart_smac_batch"] == before.get("spart_smac_batch", 0)
+    assert sp.canopyopt.rso.shape == (2162, 1) and sp.leafopt.refl.shape == (2162, 1) and sp.leafopt.kChlrel.shape == (2001, 1)
+    assert sp.soilopt.refl.shape == (2162, 1) and sp.soilopt.refl_dry.shape == (2001, 1)
+    assert eng.calls["spart_run_batch"] == before.get("spart_run_batch", 0) + 2         # one materialising call for all three
+    assert abs(sp.canopyopt.rso[400, 0] - 0.40396347479496547) < 1e-6 and abs(sp.canopyopt.rdd[2100, 0] - 0.005657296144770152) < 1e-6
+    assert abs(sp.leafopt.refl[150, 0] - 0.06375474885800862) < 1e-7 and abs(sp.soilopt.refl[400, 0] - 0.3978653598241099) < 1e-7
+    assert abs(sp.R_TOC[0, 5] / 0.3371841542003048 - 1) < 1e-6
+    eager = SPART.SPART(sp.soilpar, sp.leafbio, canopy, sp.atm, angles, "Sentinel2A-MSI", 100)
+    eager.run(materialize=True)
+    assert np.array_equal(eager.canopyopt.rso, sp.canopyopt.rso) and np.array_equal(eager.R_TOA, sp.R_TOA)
+    # a batched run: still one call, BatchResult out, lazy (B, 2162) spectra
+    many = SPART.SPART(SPART.SoilParameters(0.5, 0, 100, np.array([20.0, 30.0, 4.0]), 25, 0.015), sp.leafbio, canopy, sp.atm, angles,
+                       "Sentinel2A-MSI", 100)
+    n0 = eng.calls["spart_run_batch"]
+    res = many.run()
+    assert eng.calls["spart_run_batch"] == n0 + 1 and res["R_TOC"].shape == (3, 13) and many.canopyopt.rdd.shape == (3, 2162)
+    assert np.array_equal(res["R_TOC"][0], sp.R_TOC[0])
     assert np.array_equal(gs["Sentinel2A-MSI/angles"][0], [40, 0, 0]) and np.allclose(gs["Sentinel2A-MSI/atm"][0], [0.325, 0.35, 1.41, 1013.25])
     for f in ("Ta_s", "Ta_o", "Tg", "Ra_dd", "Ra_so", "Ta_ss", "Ta_sd", "Ta_oo", "Ta_do"):
         a = getattr(sp.atmopt, f)
