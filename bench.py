@@ -500,6 +500,11 @@ def main():
         ok = all(bool(torch.isfinite(r).all().item()) for r in res)
         if world > 1:
             ok = ok and all(bool(torch.isfinite(g).all().item()) for gl in gather_lists for g in gl)
+        # order-independent checksum of the columns as rank 0 holds them (the integer sum of their bit patterns): equal for
+        # any number of ranks when the gathered shards are exactly the single-rank result
+        bits = torch.int32 if td == torch.float32 else torch.int64
+        blocks = gather_lists[0] if world > 1 else [res[0]]
+        checksum = int(sum(int(g.view(bits).to(torch.int64).sum().item()) for g in blocks) & ((1 << 63) - 1))
         value = Bg * args.steps / dt
         stage_ms = {k: v / max(ncalls, 1) for k, v in stage.items()}
         band_kernel = "k_bands<float, 0, 1>" if args.dtype == "float32" else "k_bands<double, 0, 1>"
@@ -520,7 +525,7 @@ def main():
                                    "mode's, rounded once") if args.dtype == "float32" else "float64 throughout",
                        "tables": "17 table values per band held in VGPRs (lane = band); the per-sample constants, not the tables, "
                                  "are staged through LDS (north_star says tables in LDS; measured slower, DESIGN.md section 4)",
-                       "finite": ok},
+                       "finite": ok, "columns_checksum": checksum},
             "roofline": roofline(args.dtype, B, nb, stage_ms, dt / args.steps * 1e3, band_kernel),
         }
         line["cpu_baseline"] = cpu

@@ -38,7 +38,10 @@ def _prefault(a):
         _libc.madvise.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
     page = os.sysconf("SC_PAGE_SIZE")
     lo = a.ctypes.data & ~(page - 1)
-    return _libc.madvise(lo, a.ctypes.data + a.nbytes - lo, _MADV_POPULATE_WRITE) == 0
+    try:
+        return _libc.madvise(lo, a.ctypes.data + a.nbytes - lo, _MADV_POPULATE_WRITE) == 0
+    except Exception:               # noqa: BLE001  (pre-faulting is an optimisation: never let it fail the LUT)
+        return False
 
 
 def generate_lut(params, sensor, path=None, dtype="float32", chunk=1 << 20, device=None, prune=True, fault_threads=8,
@@ -140,7 +143,10 @@ def generate_lut(params, sensor, path=None, dtype="float32", chunk=1 << 20, devi
         j = i % 2
         lo, n = bounds(i)
         for f in faults.pop(i, ()):
-            f.result()                                             # the destination pages of this chunk are resident
+            try:
+                f.result()                                         # the destination pages of this chunk are resident
+            except Exception:       # noqa: BLE001  ("not pre-faulted": the copy below faults the pages in itself)
+                pass
         with torch.cuda.device(dev), torch.cuda.stream(d2h):
             d2h.wait_event(ev_done[j])
             for q, k in enumerate(COLUMNS):
@@ -150,25 +156,27 @@ def generate_lut(params, sensor, path=None, dtype="float32", chunk=1 << 20, devi
     # downloads (which also take the first-touch page faults of the destination) run on one helper thread so that
     # they overlap the uploads issued by this thread; torch releases the GIL inside the copies
     fut = [None, None]
-    with ThreadPoolExecutor(1) as pool:
-        prefault(0)
-        prefault(1)
-        if nchunks:
-            upload(0)
-            launch(0)
-        for i in range(nchunks):
-            prefault(i + 2)
-            if i + 1 < nchunks:
-                upload(i + 1)                                      # overlaps the kernels of chunk i
-                if fut[(i + 1) % 2] is not None:
-                    fut[(i + 1) % 2].result()                      # dout[(i+1) % 2] has been drained (chunk i-1)
-                launch(i + 1)
-            fut[i % 2] = pool.submit(download, i)                  # overlaps the kernels of chunk i+1
-        for f in fut:
-            if f is not None:
-                f.result()
-    if fpool is not None:
-        fpool.shutdown()
+    try:
+        with ThreadPoolExecutor(1) as pool:
+            prefault(0)
+            prefault(1)
+            if nchunks:
+                upload(0)
+                launch(0)
+            for i in range(nchunks):
+                prefault(i + 2)
+                if i + 1 < nchunks:
+                    upload(i + 1)                                  # overlaps the kernels of chunk i
+                    if fut[(i + 1) % 2] is not None:
+                        fut[(i + 1) % 2].result()                  # dout[(i+1) % 2] has been drained (chunk i-1)
+                    launch(i + 1)
+                fut[i % 2] = pool.submit(download, i)              # overlaps the kernels of chunk i+1
+            for f in fut:
+                if f is not None:
+                    f.result()
+    finally:                                                       # also on an exception in upload / launch / download
+        if fpool is not None:
+            fpool.shutdown(wait=True, cancel_futures=True)
     if path is not None:
         for a in out.values():
             a.flush()

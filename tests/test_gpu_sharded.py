@@ -105,3 +105,32 @@ def test_two_gloo_ranks_with_the_hip_evaluator_match_single_rank():
         assert p.exitcode == 0
     assert shape == (3, B, 13) and finite
     assert same                                                    # shards are independent: bit-identical to one rank
+
+
+def test_bench_under_the_drivers_multi_rank_invocation():
+    """The driver's exact N > 1 command line -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W` -- as a fresh child process, with two ranks sharing
+    the one GPU of the test box under gloo (SPART_BENCH_BACKEND=gloo; the driver's run uses the default nccl = RCCL on N
+    GPUs, which nothing here can measure): one JSON line from rank 0, strong scaling of ONE global table cut into contiguous
+    shards, finite, and the throughput of the shard + double-buffered gather path consistent with the single-rank line of
+    the same batch (both ranks share the GPU, so no speed-up is expected -- only that nothing is lost or counted twice)."""
+    import json
+    import subprocess
+    env = dict(os.environ, SPART_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = ["--batch", "200000", "--steps", "3", "--warmup", "1", "--cpu-rows", "0", "--no-extras"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", *common], env=env, capture_output=True,
+                         text=True, timeout=600, cwd=ROOT)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", *common],
+                         env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert two.returncode == 0, two.stderr[-2000:]
+    l1 = [json.loads(l) for l in one.stdout.splitlines() if l.startswith("{")]
+    l2 = [json.loads(l) for l in two.stdout.splitlines() if l.startswith("{")]
+    assert len(l1) == 1 and len(l2) == 1                          # rank 0 prints ONE line
+    a, b = l1[0], l2[0]
+    assert b["n_gpus"] == 2 and b["scaling"] == "strong" and b["steps"] == 3 and b["warmup"] == 1
+    assert b["config"]["global_batch"] == 200000 and b["config"]["batch_per_gpu"] == 100000 and b["config"]["finite"] is True
+    assert b["metric"] == a["metric"] and b["unit"] == "spectra/s" and b["config"]["build_id"] == a["config"]["build_id"]
+    assert b["config"]["columns_checksum"] == a["config"]["columns_checksum"]       # the gathered columns ARE the single-rank columns
+    assert 0.3 * a["value"] < b["value"] < 1.5 * a["value"], (a["value"], b["value"])
