@@ -334,7 +334,15 @@ def mode_records(torch, args, dev):
     r["workload"] = (f"prune_unused_bands = 1: prelude + float64 sensor-slot pass ({eng.nb} of 2162 bands) + SMAC / TOC->TOA, 1M spectra, "
                      f"{args.sensor}; NOT full spectra -- reported as the cost of the returned columns, never as the headline")
     rec["pruned"] = r
-    del full, pr
+    # --- fast_prelude (lidf="newton"): the documented speed / agreement trade of the per-sample prelude, full evaluation
+    fp = run_config(torch, eng, Pd, "float32", 10, 2, lidf="newton")
+    nw = eng.run(Pd, "float32", lidf="newton")
+    fp["max_rel_dev_from_default_columns_floor1e-6"] = {k: float(((nw[k].double() - full[k].double()).abs() / full[k].double().abs().clamp_min(1e-6)).max().item())
+                                                         for k in full}
+    fp["workload"] = ("spart_materialize.fast_prelude = 1 (Engine.run(lidf='newton')): exact root of the LIDF equation + 8-point hot-spot "
+                      "panels instead of the reference's stopped iteration; all 2162 bands evaluated; 1M spectra, fp32")
+    rec["fast_prelude"] = fp
+    del full, pr, nw
     # --- LUT inversion: 1M-row LUT (this run's R_TOC columns) x 65 536 observations, float32
     lut = eng.run(Pd, "float32")["R_TOC"].clone()
     M = 65536

@@ -102,6 +102,12 @@ typedef struct spart_materialize {
                                   to the float64 mode's -- they come from the same float64 column path -- while the
                                   evaluation of all 2162 bands of every sample (the band sums) runs in float32.
                                   Materialised spectra, band_mean and rdry_in cannot be combined with it (SPART_ERR_INVALID). */
+  int32_t fast_prelude;        /* 0 (default): the reference's own LIDF fixed-point iteration with its |dx| <= 1e-8 stopping rule
+                                  (sailh.py:378-382) and 10-point hot-spot panels -- the columns agree with the reference to
+                                  ~1e-11.  1: the root of the same equation by Newton (the reference stops up to ~5e-8 short
+                                  of it) and 8-point panels: R_TOC / R_TOA / L_TOA move by <= 1e-7 relative (inside the
+                                  1e-6 / 1e-4 contract; measured per run in bench.py configs.fast_prelude), the per-sample
+                                  prelude kernel takes half the time (0.93 -> 0.45 ms per 1M spectra) */
 } spart_materialize;
 
 int spart_ctx_create(spart_ctx **out, int device, const spart_tables *tables);

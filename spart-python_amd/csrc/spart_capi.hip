@@ -311,7 +311,7 @@ static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_
     Range r("SPART prelude (geometry, LIDF, hot spot, soil factors)");
     // legacy float32 columns (TG = float): the fast prelude; otherwise the literal one.  cstF only when a float32
     // full-band kernel (or the float32 slot pass) will read it.
-    rc = launch_prelude(ctx, sizeof(TG) == 4, pp, PRE_ALL, B, Bp, (sizeof(TG) == 4 || (sizeof(T) == 4 && bands)) ? cstF : nullptr,
+    rc = launch_prelude(ctx, sizeof(TG) == 4 || (opt && opt->fast_prelude), pp, PRE_ALL, B, Bp, (sizeof(TG) == 4 || (sizeof(T) == 4 && bands)) ? cstF : nullptr,
                         sizeof(TG) == 8 ? cstD : nullptr, atm, st);
   }
   if (rc) return rc;

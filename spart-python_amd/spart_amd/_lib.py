@@ -23,7 +23,8 @@ class SpartMaterialize(ctypes.Structure):
     _fields_ = [(n, vp) for n in ("leaf_refl", "leaf_tran", "leaf_kchl", "soil_refl", "soil_refl_dry", "rso", "rdo",
                                   "rsd", "rdd", "rsoil", "La", "rdry_in", "band_mean")] + [("prune_unused_bands", ctypes.c_int32),
                                                                                           ("f32_columns", ctypes.c_int32),
-                                                                                          ("f32_bands", ctypes.c_int32)]
+                                                                                          ("f32_bands", ctypes.c_int32),
+                                                                                          ("fast_prelude", ctypes.c_int32)]
 
 
 # name -> (restype, argtypes): every symbol include/spart_hip.h declares

@@ -227,7 +227,7 @@ class Engine:
         return dict(zip(SMAC_FIELDS, out))
 
     def run(self, params, dtype="float32", rho_thermal=None, tau_thermal=None, materialize=(), out=None,
-            prune=False, rdry=None, f32_columns=False, f32_bands=False, _workspace=None):
+            prune=False, rdry=None, f32_columns=False, f32_bands=False, lidf="literal", _workspace=None):
         """SPART(...).run() for every column of ``params`` (SPART.py:162-269).
 
         params : (27, B) float64 device tensor (rows = spart_amd.workloads.PARAM_NAMES) or a list of 27
@@ -241,6 +241,9 @@ class Engine:
                the B / lat / lon entries of ``params`` are then ignored (may be None in a list)
         f32_bands : float64 only.  True: float64 columns identical to the float64 mode's over a float32 evaluation of
                the 2162 bands (spart_materialize.f32_bands): reference precision at the float32 mode's speed
+        lidf : "literal" (default) = the reference's LIDF fixed-point iteration with its stopping rule and 10-point hot-spot
+               panels; "newton" = spart_materialize.fast_prelude: the exact root + 8-point panels, columns within 1e-7
+               relative of the default, the prelude kernel twice as fast
         f32_columns : float32 only.  False (default): the bands the sensor columns depend on are re-evaluated in
                float64, the columns are the float64 mode's values rounded to float32; True: columns straight from
                the float32 band arithmetic (spart_materialize.f32_columns)
@@ -272,8 +275,11 @@ class Engine:
                 self._check_out(k, res[k], (B, self.nb), td)
         mat = None
         rd = None
-        if materialize or prune or rdry is not None or f32_columns or f32_bands:
+        if lidf not in ("literal", "newton"):
+            raise ValueError("lidf must be 'literal' or 'newton'")
+        if materialize or prune or rdry is not None or f32_columns or f32_bands or lidf == "newton":
             mat = _lib.SpartMaterialize()
+            mat.fast_prelude = 1 if lidf == "newton" else 0
             mat.prune_unused_bands = 1 if prune else 0
             mat.f32_columns = 1 if f32_columns else 0
             mat.f32_bands = 1 if f32_bands else 0

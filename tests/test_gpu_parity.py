@@ -759,6 +759,24 @@ def test_lut_inversion_matches_brute_force(dtype, nb, torch_mod):
             assert list(idx[:5]) == [100, 101, 102, 103, 104] and np.all(cost[:5] == 0.0)
 
 
+def test_fast_prelude_option_stays_inside_the_contract(golden, torch_mod):
+    """Engine.run(lidf="newton") = spart_materialize.fast_prelude: the exact root of the LIDF equation (the reference stops its
+    iteration up to ~5e-8 short, sailh.py:378-382) and 8-point hot-spot panels.  Against the REFERENCE's golden rows the
+    columns must still meet the 1e-6 contract, and stay within 1e-6 of the default (literal) evaluation."""
+    from spart_amd import get_engine
+    g = golden["e2e"]
+    for name, sensor in (("lhs_full/Sentinel2A-MSI", "Sentinel2A-MSI"), ("lhs_pro/Sentinel2B-MSI", "Sentinel2B-MSI")):
+        eng = get_engine(sensor, 0)
+        P = torch_mod.as_tensor(g[name + "/P"].T.copy(), device="cuda:0")
+        lit, fast = eng.run(P, "float64"), eng.run(P, "float64", lidf="newton")
+        for k in ("R_TOC", "R_TOA", "L_TOA"):
+            assert rel_err(fast[k].cpu().numpy(), g[f"{name}/{k}"], COLFLOOR) < 1e-6, (name, k)
+            d = rel_err(fast[k].cpu().numpy(), lit[k].cpu().numpy(), COLFLOOR)
+            assert 0 < d < 1e-6, (name, k, d)             # (it IS a different prelude)
+    with pytest.raises(ValueError):
+        eng.run(P, "float64", lidf="bisect")
+
+
 def test_lut_inversion_small_and_tied(torch_mod):
     """Sizes below one MFMA tile / one observation block, duplicate rows (ties go to the lowest row index, also across
     32-row tiles and across slices), an all-NaN LUT and a NaN observation (index -1, cost inf)."""

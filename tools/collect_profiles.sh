@@ -27,6 +27,16 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/c2_pmc_fetch
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/c2_pmc_write -- python3 $R/tools/prospect_bench.py 10000 float64 5 > $O/c2_pmc_write.log 2>&1
 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/c2_pmc_sq -- python3 $R/tools/prospect_bench.py 10000 float64 5 > $O/c2_pmc_sq.log 2>&1
 echo config2 done
+# the modes beside the headline (bench.py configs.materialized / lut_invert / pruned): stats + counter passes over tools/mode_run.py
+MFMA="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SALU GRBM_GUI_ACTIVE"
+for M in materialized lut_invert pruned; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/${M}_stats -- python3 $R/tools/mode_run.py $M 10 > $O/${M}_stats.log 2>&1
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${M}_pmc_fetch -- python3 $R/tools/mode_run.py $M 3 > $O/${M}_pmc_fetch.log 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${M}_pmc_write -- python3 $R/tools/mode_run.py $M 3 > $O/${M}_pmc_write.log 2>&1
+  if [ $M = lut_invert ]; then C="$MFMA"; else C="$SQ"; fi
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/${M}_pmc_sq -- python3 $R/tools/mode_run.py $M 3 > $O/${M}_pmc_sq.log 2>&1
+  echo $M done
+done
 # FETCH_SIZE / WRITE_SIZE calibration on known byte counts in this library's access widths
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/calib_fetch -- $R/tools/ubench/fetch_calib > $O/calib_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/calib_write -- $R/tools/ubench/fetch_calib > $O/calib_write.log 2>&1
@@ -36,4 +46,18 @@ timeout -k 10 120 python tools/prospect_bench.py 1000000 float64 5 >> $O/c2_benc
 timeout -k 10 120 python tools/prospect_bench.py 1000000 float32 5 >> $O/c2_bench.txt 2>&1
 timeout -k 10 300 python tools/mode_cost.py > $O/mode_cost.txt 2>&1
 timeout -k 10 300 python tools/lut_rate.py > $O/lut_rate.txt 2>&1
+timeout -k 10 300 python tools/lut_invert_rate.py > $O/lut_invert_rate.txt 2>&1
+timeout -k 10 300 python tools/mat_bench.py > $O/mat_bench.txt 2>&1
+# package power / clock while the materialised mode runs (it is power-bound: DESIGN.md section 4)
+python3 $R/tools/mode_run.py materialized 7000 > $O/power_materialized.run 2>&1 &
+PID=$!
+sleep 12
+for i in 1 2 3 4 5 6; do rocm-smi --showpower --showclocks 2>&1 | grep -i "Power (W)\|sclk"; sleep 0.5; done > $O/power_materialized.txt 2>&1
+wait $PID
+python3 $R/tools/mode_run.py headline 1200 > $O/power_headline.run 2>&1 &
+PID=$!
+sleep 10
+for i in 1 2 3 4 5 6; do rocm-smi --showpower --showclocks 2>&1 | grep -i "Power (W)\|sclk"; sleep 0.5; done > $O/power_headline.txt 2>&1
+wait $PID
+rocm-smi --showmaxpower 2>&1 | grep -i "power" > $O/power_cap.txt
 echo done > $O/DONE

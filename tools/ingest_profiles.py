@@ -110,6 +110,44 @@ for dt in ("float32", "float64"):
         shutil.copy(f, os.path.join(dst, f"{tag}_kernel_stats_{dt}.csv"))
     print(dt, {k: (round(v["hbm_bytes"] / 1e6, 1), round(v.get("SQ_INSTS_VALU", 0) / 1e9, 3)) for k, v in kern.items()})
 
+# ---- the modes beside the headline (tools/mode_run.py): one counter file each, read by bench.py's mode records
+MODE_BATCH = {"materialized": 200_000, "pruned": 1_000_000, "lut_invert": 1_000_000}
+for mode, batch in MODE_BATCH.items():
+    kern = collections.defaultdict(dict)
+    for d in ("fetch", "write", "sq"):
+        f = one(f"{mode}_pmc_{d}/*/*_counter_collection.csv")
+        if not f:
+            continue
+        shutil.copy(f, os.path.join(dst, f"{tag}_{mode}_pmc_{d}.csv"))
+        for k, v in per_kernel(f).items():
+            if k.startswith("k_"):
+                for cn, val in v.items():
+                    kern[k][cn if cn not in ("FETCH_SIZE", "WRITE_SIZE") else cn + "_KB"] = val
+    f = one(f"{mode}_stats/*/*_kernel_stats.csv")
+    if f:
+        shutil.copy(f, os.path.join(dst, f"{tag}_{mode}_kernel_stats.csv"))
+        for r in csv.DictReader(open(f)):
+            k = r["Name"].split("(")[0].replace("void ", "").replace("spart::", "")
+            if k in kern:
+                kern[k]["avg_ms"] = float(r["AverageNs"]) / 1e6
+                kern[k]["calls"] = int(r["Calls"])
+    if not kern:
+        continue
+    for k, v in kern.items():
+        # materialised spectra: 4-byte coalesced stores (1.00), constants read as 128-byte segments; the LUT tiles are read as
+        # coalesced 4-byte loads (gfx950 tallies them at 1/2) -- and mostly from L2 / Infinity Cache, which FETCH_SIZE counts too
+        fr = corr("r", "seg") if k.startswith("k_bands") else corr("r", 4 if "lut" in k else 8)
+        fw = corr("w", 4) if (k.startswith("k_bands") or "lut" in k) else corr("w", 8)
+        v["fetch_bytes"] = v.get("FETCH_SIZE_KB", 0.0) * 1024 / fr
+        v["write_bytes"] = v.get("WRITE_SIZE_KB", 0.0) * 1024 / fw
+        v["hbm_bytes"] = v["fetch_bytes"] + v["write_bytes"]
+        v["calibration"] = {"fetch": fr, "write": fw}
+    json.dump({"src_hash": src_hash(), "batch": batch, "nb": 13, "mode": mode,
+               "command": f"rocprofv3 --kernel-trace --stats | --pmc <FETCH_SIZE | WRITE_SIZE | SQ set> -- python3 tools/mode_run.py {mode} "
+                          f"(separate passes, tools/collect_profiles.sh {tag})", "kernels": kern},
+              open(os.path.join(dst, f"{prefix}_counters_{mode}.json"), "w"), indent=1)
+    print(mode, {k: (round(v["hbm_bytes"] / 1e6, 1), round(v.get("avg_ms", 0), 3)) for k, v in kern.items()})
+
 # ---- config 2 (PROSPECT-only kernel at 10k x 2001 float64)
 c2 = {}
 for d in ("fetch", "write", "sq"):
@@ -126,7 +164,8 @@ if c2:
     json.dump({"src_hash": src_hash(), "batch": 10_000, "kernels": c2,
                "_note": "per launch, BASELINE config 2 (tools/prospect_bench.py 10000 float64); FETCH_SIZE / WRITE_SIZE in KB as reported"},
               open(os.path.join(dst, f"{tag}_c2_counters.json"), "w"), indent=1)
-for name in ("bench.json", "c2_bench.txt", "mode_cost.txt", "lut_rate.txt"):
+for name in ("bench.json", "c2_bench.txt", "mode_cost.txt", "lut_rate.txt", "lut_invert_rate.txt", "mat_bench.txt", "power_materialized.txt",
+             "power_headline.txt", "power_cap.txt"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, f"{tag}_{name}"))
 print(json.dumps(calib, indent=1))
