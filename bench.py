@@ -153,6 +153,8 @@ def stage_view(stage_ms, dtype, f32_bands=False, pruned=False):
     fork / join), so their events measure when they finished relative to the end of the prelude, not how long they would
     take alone: they are shown as one entry, `columns_beside_bands`, and the step is prelude + max(bands,
     columns_beside_bands)."""
+    if "slots" not in stage_ms:                       # (already a view)
+        return dict(stage_ms)
     if not pruned and os.environ.get("SPART_SIDE_STREAM", "1") != "0":
         return {"prelude": stage_ms["prelude"], "bands": stage_ms["bands"],
                 "columns_beside_bands": stage_ms["slots"] + stage_ms["sensor"]}

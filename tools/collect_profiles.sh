@@ -28,7 +28,7 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/c2_pmc_write
 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/c2_pmc_sq -- python3 $R/tools/prospect_bench.py 10000 float64 5 > $O/c2_pmc_sq.log 2>&1
 echo config2 done
 # the modes beside the headline (bench.py configs.materialized / lut_invert / pruned): stats + counter passes over tools/mode_run.py
-MFMA="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SALU GRBM_GUI_ACTIVE"
+MFMA="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"
 for M in materialized lut_invert pruned; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/${M}_stats -- python3 $R/tools/mode_run.py $M 10 > $O/${M}_stats.log 2>&1
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${M}_pmc_fetch -- python3 $R/tools/mode_run.py $M 3 > $O/${M}_pmc_fetch.log 2>&1
