@@ -186,8 +186,9 @@ __device__ __forceinline__ double spart_horner(double p, double x, double c_unif
 //    (csrc/spart_f64_tables.h, mpmath) sit in LDS: 6 KB per workgroup, staged by stage_f64_tables() at kernel entry;
 //    the lookups are per-lane ds_reads (neighbouring bands mostly hit the same entry: broadcast).  EVERY kernel that
 //    evaluates band arithmetic in float64 must call stage_f64_tables() first.
-//    exp(x) is 0 below x = -745 (including -inf), NaN propagates; log is only called with positive finite normal
-//    arguments (a NaN stays a NaN).  Relative error <= 3e-16 (exp), absolute <= 3e-16 / relative <= 2e-15 away from
+//    exp(x) is 0 below x = -745 (including -inf); log is only called with positive finite normal arguments.  Neither
+//    propagates a NaN argument by itself: in leaf_band / soil_band / canopy_core every result of exp / log is multiplied
+//    with terms that are NaN when the argument is (test_nan_and_nonphysical_inputs_do_not_crash).  Relative error <= 3e-16 (exp), absolute <= 3e-16 / relative <= 2e-15 away from
 //    x = 1 (log).
 __device__ __constant__ double c_EXP_F64[12] = {1.0 / 2, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320,
                                                 1.0 / 362880, 1.0 / 3628800, 1.0 / 39916800, 1.0 / 479001600, 1.0 / 6227020800.0};
@@ -240,7 +241,8 @@ template <> struct Mx<double> {
     return __builtin_ldexp(__builtin_fma(t, p, t), ki >> 8);
   }
   static SPART_HD double exp(double x) {
-    x = (x < -800.0) ? -800.0 : x;                          // e^-800 underflows to 0 in ldexp; a NaN stays a NaN
+    x = __builtin_fmax(x, -800.0);      // e^-800 underflows to 0 in ldexp.  (One v_max instead of a compare + two selects; a NaN
+                                        //  argument gives 0 here -- every caller multiplies the result with NaN terms anyway)
     const double k = __builtin_rint(x * 369.32993046757463);             // 256 / ln 2
     double r = __builtin_fma(-k, 0.0027076061737716373, x);              // ln2/256, high part (33 bits: k * hi is exact)
     r = __builtin_fma(-k, 2.9064910585985925e-13, r);                    // low part
@@ -258,7 +260,7 @@ template <> struct Mx<double> {
     const unsigned i = (hi >> 12) & (unsigned)(F64_LOG_TAB - 1);
     const double m = __longlong_as_double((long long)((u & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull));   // [1, 2)
     const double R = s_f64_log_tab[2 * i], L = s_f64_log_tab[2 * i + 1];  // one ds_read_b128
-    const double z = __builtin_fma(m, R, -1.0) + x * 0.0;   // (x * 0: a NaN / inf argument gives NaN instead of a finite value)
+    const double z = __builtin_fma(m, R, -1.0);             // (a NaN / inf argument gives a finite value: see the callers)
     double q = spart_horner(-1.0 / 6.0, z, 0.2);
     q = spart_horner(q, z, -0.25);
     q = spart_horner(q, z, 1.0 / 3.0);
@@ -272,27 +274,25 @@ template <> struct Mx<double> {
   static SPART_HD double exp2(double x) { return ::exp2(x); }
   static SPART_HD double log(double x) { return ::log(x); }
 #endif
-  // square root: v_rsq_f64 (4.6e-8 relative) refined by ONE third-order step, sqrt x = g (1 + e/2 + 3 e^2/8 + O(e^3)),
-  // g = x y0, e = 1 - g y0: 6 instructions + a class test for 0 / inf, against ~14 of the library's sequence
+  // square root: v_rsq_f64 (4.6e-8 relative) refined by ONE Newton step, sqrt x = g (1 + e/2 + O(e^2)), g = x y0,
+  // e = 1 - g y0: relative error 3 e^2 / 8 < 1e-15 in 5 instructions (the library's sequence: ~14).  The argument of the
+  // rsq is kept away from 0 (x = 0 -> 0 * rsq(tiny) = 0 instead of 0 * inf); a NaN x stays NaN through g.
   static SPART_HD double sqrt(double x) {
 #if defined(__HIP_DEVICE_COMPILE__) && defined(SPART_FAST_MATH)
-    const double y0 = __builtin_amdgcn_rsq(x);
+    const double y0 = __builtin_amdgcn_rsq(__builtin_fmax(x, 1e-300));
     const double g = x * y0;
     const double e = __builtin_fma(-g, y0, 1.0);
-    const double s = __builtin_fma(g, e * __builtin_fma(0.375, e, 0.5), g);
-    return __builtin_amdgcn_class(x, 0x260) ? x : s;        // +-0 and +inf pass through; negative -> NaN (v_rsq)
+    return __builtin_fma(g * 0.5, e, g);
 #else
     return ::sqrt(x);
 #endif
   }
-  // reciprocal: v_rcp_f64 (4.6e-8 relative, tools/ubench/rcp64_probe) refined by ONE second-order step,
-  // 1/x = r (1 + e + e^2 + O(e^3)), e = 1 - x r: 4 instructions and the last bit (two Newton steps: 5; the IEEE division
-  // sequence: ~12); the host build divides
+  // reciprocal: v_rcp_f64 (4.6e-8 relative, tools/ubench/rcp64_probe) refined by ONE Newton step r (2 - x r):
+  // relative error e^2 = 2e-15 in 3 instructions (the IEEE division sequence: ~12); the host build divides
   static SPART_HD double rcp(double x) {
 #if defined(__HIP_DEVICE_COMPILE__) && defined(SPART_FAST_MATH)
     const double r = __builtin_amdgcn_rcp(x);
-    const double e = __builtin_fma(-x, r, 1.0);
-    return __builtin_fma(__builtin_fma(e, e, e), r, r);
+    return __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
 #else
     return 1.0 / x;
 #endif
@@ -461,6 +461,30 @@ template <typename T> SPART_HD void plate_tau(T K, T& tau, T& u) {
   // zero-absorption limit (prospect_5d.py:233-235) continuously.  NaN propagates.
   T x = (K < Mx<T>::tiny()) ? Mx<T>::tiny() : K;   // (a select, not fmax: a NaN K must stay NaN)
   const bool small = x < T(1);
+  if (sizeof(T) == 8) {   // float64: tau and u formed in each branch (a select of a double is two instructions)
+    T tl, ul;             // (locals, not the reference arguments: those made the compiler route the values through scratch)
+    if (small) {
+      const auto cg = C::gt();
+      T g = cg[C::GD];
+#pragma unroll
+      for (int i = C::GD - 1; i >= 0; --i) g = horner_uniform(g, x, cg[i]);
+      ul = x * (g + x * Mx<T>::log(x));
+      tl = T(1) - ul;
+    } else {
+      const auto cp = C::pt(), cq = C::qt();
+      T pn = C::PSCALE * cp[0], qn = cq[0];
+#pragma unroll
+      for (int i = 1; i <= C::WD; ++i) {
+        pn = horner_uniform(pn, x, C::PSCALE * cp[i]);
+        qn = horner_uniform(qn, x, cq[i]);
+      }
+      tl = Mx<T>::exp(-x) * pn * Mx<T>::rcp((x + T(3)) * qn);
+      ul = T(1) - tl;
+    }
+    tau = tl;
+    u = ul;
+    return;
+  }
   T v;  // u on the small branch, tau on the large one (one value, so nothing is spilled to select them)
   if (small) {
     const auto cg = C::gt();
