@@ -48,6 +48,7 @@ timeout -k 10 300 python tools/mode_cost.py > $O/mode_cost.txt 2>&1
 timeout -k 10 300 python tools/lut_rate.py > $O/lut_rate.txt 2>&1
 timeout -k 10 300 python tools/lut_invert_rate.py > $O/lut_invert_rate.txt 2>&1
 timeout -k 10 300 python tools/mat_bench.py > $O/mat_bench.txt 2>&1
+timeout -k 10 300 python tools/fast_prelude_dev.py > $O/fast_prelude_dev.txt 2>&1
 # package power / clock while the materialised mode runs (it is power-bound: DESIGN.md section 4)
 python3 $R/tools/mode_run.py materialized 7000 > $O/power_materialized.run 2>&1 &
 PID=$!

@@ -164,7 +164,7 @@ if c2:
     json.dump({"src_hash": src_hash(), "batch": 10_000, "kernels": c2,
                "_note": "per launch, BASELINE config 2 (tools/prospect_bench.py 10000 float64); FETCH_SIZE / WRITE_SIZE in KB as reported"},
               open(os.path.join(dst, f"{tag}_c2_counters.json"), "w"), indent=1)
-for name in ("bench.json", "c2_bench.txt", "mode_cost.txt", "lut_rate.txt", "lut_invert_rate.txt", "mat_bench.txt", "power_materialized.txt",
+for name in ("bench.json", "c2_bench.txt", "mode_cost.txt", "lut_rate.txt", "lut_invert_rate.txt", "mat_bench.txt", "fast_prelude_dev.txt", "power_materialized.txt",
              "power_headline.txt", "power_cap.txt"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, f"{tag}_{name}"))
