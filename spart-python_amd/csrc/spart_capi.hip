@@ -209,8 +209,12 @@ static int prospect_impl(spart_ctx* ctx, int64_t B, const double* const leaf[9],
   int64_t nchunk = (B + chunk - 1) / chunk;
   const T* tab = sizeof(T) == 4 ? (const T*)ctx->tabF : (const T*)ctx->tabD;
   if (!chunk_fits_32bit(chunk, ctx->po, sizeof(T))) return fail(ctx, SPART_ERR_INVALID, "batch too large for one call");
-  hipLaunchKernelGGL((k_prospect<T>), dim3(xcd_grid(nchunk)), dim3(TILE), 0, st, tab, (const T*)cst, ws.Bp, B, chunk,
-                     ctx->po, (T*)refl, (T*)tran, (T*)kchl);
+  if (nt_ok(ctx->po, sizeof(T)))
+    hipLaunchKernelGGL((k_prospect<T, true>), dim3(xcd_grid(nchunk)), dim3(TILE), 0, st, tab, (const T*)cst, ws.Bp, B, chunk,
+                       ctx->po, (T*)refl, (T*)tran, (T*)kchl);
+  else
+    hipLaunchKernelGGL((k_prospect<T, false>), dim3(xcd_grid(nchunk)), dim3(TILE), 0, st, tab, (const T*)cst, ws.Bp, B, chunk,
+                       ctx->po, (T*)refl, (T*)tran, (T*)kchl);
   HIP_TRY(ctx, hipGetLastError());
   return SPART_OK;
 }
@@ -228,8 +232,12 @@ static int bsm_impl(spart_ctx* ctx, int64_t B, const double* const soil[6], cons
   int64_t nchunk = (B + chunk - 1) / chunk;
   const T* tab = sizeof(T) == 4 ? (const T*)ctx->tabF : (const T*)ctx->tabD;
   if (!chunk_fits_32bit(chunk, ctx->po, sizeof(T))) return fail(ctx, SPART_ERR_INVALID, "batch too large for one call");
-  hipLaunchKernelGGL((k_bsm<T>), dim3(xcd_grid(nchunk)), dim3(TILE), 0, st, tab, (const T*)cst, ws.Bp, B, chunk,
-                     ctx->po, (const T*)rdry_in, (T*)refl, (T*)dry);
+  if (nt_ok(ctx->po, sizeof(T)))
+    hipLaunchKernelGGL((k_bsm<T, true>), dim3(xcd_grid(nchunk)), dim3(TILE), 0, st, tab, (const T*)cst, ws.Bp, B, chunk,
+                       ctx->po, (const T*)rdry_in, (T*)refl, (T*)dry);
+  else
+    hipLaunchKernelGGL((k_bsm<T, false>), dim3(xcd_grid(nchunk)), dim3(TILE), 0, st, tab, (const T*)cst, ws.Bp, B, chunk,
+                       ctx->po, (const T*)rdry_in, (T*)refl, (T*)dry);
   HIP_TRY(ctx, hipGetLastError());
   return SPART_OK;
 }
@@ -248,8 +256,12 @@ static int sailh_impl(spart_ctx* ctx, int64_t B, const void* rho, const void* ta
   int chunk = pick_chunk(B);
   int64_t nchunk = (B + chunk - 1) / chunk;
   if (!chunk_fits_32bit(chunk, ctx->pf, sizeof(T))) return fail(ctx, SPART_ERR_INVALID, "batch too large for one call");
-  hipLaunchKernelGGL((k_sailh<T>), dim3((unsigned)(nchunk * NTILE_FULL)), dim3(TILE), 0, st, (const T*)cst, ws.Bp, B, chunk,
-                     ctx->pf, (const T*)rho, (const T*)tau, (const T*)rs, (T*)out4[0], (T*)out4[1], (T*)out4[2], (T*)out4[3]);
+  if (nt_ok(ctx->pf, sizeof(T)))
+    hipLaunchKernelGGL((k_sailh<T, true>), dim3((unsigned)(nchunk * NTILE_FULL)), dim3(TILE), 0, st, (const T*)cst, ws.Bp, B, chunk,
+                       ctx->pf, (const T*)rho, (const T*)tau, (const T*)rs, (T*)out4[0], (T*)out4[1], (T*)out4[2], (T*)out4[3]);
+  else
+    hipLaunchKernelGGL((k_sailh<T, false>), dim3((unsigned)(nchunk * NTILE_FULL)), dim3(TILE), 0, st, (const T*)cst, ws.Bp, B, chunk,
+                       ctx->pf, (const T*)rho, (const T*)tau, (const T*)rs, (T*)out4[0], (T*)out4[1], (T*)out4[2], (T*)out4[3]);
   HIP_TRY(ctx, hipGetLastError());
   return SPART_OK;
 }
@@ -282,6 +294,7 @@ static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_
   MatPtrs<T> mp;
   std::memset(&mp, 0, sizeof(mp));
   mp.pf = ctx->pf; mp.po = ctx->po;
+  const bool nt = nt_ok(ctx->pf, sizeof(T)) && nt_ok(ctx->po, sizeof(T));     // both row grids on the 128-byte lines
   bool mat = false;
   const bool want_rsoil = opt && opt->rsoil;
   if (opt) {
@@ -344,8 +357,11 @@ static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_
     return SPART_OK;
   };
   auto band_kernels = [&]() -> int {           // the full-band kernel (+ the batch-mean reduction), on the caller's stream
-#define SPART_LAUNCH_BANDS(M, F) \
-  hipLaunchKernelGGL((k_bands<T, M, F>), grid, dim3(TILE), 0, st, tab, cst, Bp, B, chunk, mp, bsum)
+#define SPART_LAUNCH_BANDS(M, F)                                                                                          \
+  do {                                                                                                                    \
+    if ((M) != 0 && nt) hipLaunchKernelGGL((k_bands<T, M, F, (M) != 0>), grid, dim3(TILE), 0, st, tab, cst, Bp, B, chunk, mp, bsum); \
+    else hipLaunchKernelGGL((k_bands<T, M, F, false>), grid, dim3(TILE), 0, st, tab, cst, Bp, B, chunk, mp, bsum);        \
+  } while (0)
     if (mat && mp.rdry_in && full && four) SPART_LAUNCH_BANDS(2, 2);
     else if (mat && mp.rdry_in && full) SPART_LAUNCH_BANDS(2, 1);
     else if (mat && mp.rdry_in) SPART_LAUNCH_BANDS(2, 0);

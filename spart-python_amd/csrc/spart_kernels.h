@@ -149,18 +149,19 @@ template <typename T, typename C> __device__ __forceinline__ CanopyPar<T> load_c
 // per output array, 22 VGPRs for 11 arrays) is what lets the materialising kernel run at the occupancy of the
 // columns-only one.
 // Spectrum rows are written once and never read back by the kernel that writes them: non-temporal stores (the `nt` bit)
-// keep them from displacing the constants / tables in the caches.  Interleaved A/B on one box (tools/mat_ab.py,
-// tools/prospect_bench.py): materialised band kernel 3.15 -> 3.05 ms, k_prospect<double> 10k 0.182 -> 0.177 ms.
-#ifndef SPART_NT_STORES
-#define SPART_NT_STORES 1
-#endif
-template <typename T> __device__ __forceinline__ void store_row(T* row, unsigned byte_off, T v) {
-#if SPART_NT_STORES
-  __builtin_nontemporal_store(v, reinterpret_cast<T*>(reinterpret_cast<char*>(row) + byte_off));
-#else
-  *reinterpret_cast<T*>(reinterpret_cast<char*>(row) + byte_off) = v;
-#endif
+// keep them from displacing the constants / tables in the caches -- WHEN every 256-byte wave store covers whole 128-byte
+// lines, i.e. when the row pitch keeps rows on the line grid (spart_ctx_set_row_pitch; the Python engine's default).
+// Interleaved A/B on one box (tools/mat_ab.py, tools/prospect_bench.py): materialised band kernel 3.15 -> 3.05 ms,
+// k_prospect<double> 10k 0.182 -> 0.177 ms.  With DENSE rows (8648-byte pitch: the stores straddle lines) the same bit
+// defeats the write combining in L2 and costs 20 % (3.9 -> 4.8 ms), so NT is a template parameter of the storing kernels
+// that the host picks from the pitch (nt_ok below; as a run-time flag its branches cost what the bit gains); the thermal
+// pad (unaligned tails) always uses plain stores.
+template <bool NT = false, typename T> __device__ __forceinline__ void store_row(T* row, unsigned byte_off, T v) {
+  T* p = reinterpret_cast<T*>(reinterpret_cast<char*>(row) + byte_off);
+  if (NT) __builtin_nontemporal_store(v, p);
+  else *p = v;
 }
+inline bool nt_ok(int pitch_elems, size_t elem_size) { return ((size_t)pitch_elems * elem_size) % 128 == 0; }
 
 template <typename T> struct MatPtrs {
   T *leaf_refl, *leaf_tran, *leaf_kchl, *soil_refl, *soil_dry, *rso, *rdo, *rsd, *rdd;
@@ -190,7 +191,7 @@ template <typename T> struct MatPtrs {
 // The sensor columns never come from this kernel: in every mode R_TOC / R_TOA / L_TOA (and the debug rsoil column) are
 // produced by k_slots -> k_sensor from the <= 2 nb bands they depend on, so that they are the SAME numbers -- by
 // construction, not by compiler luck -- whether the full spectra are evaluated in float64, in float32, or not at all.
-template <typename T, int MAT, int FULL>
+template <typename T, int MAT, int FULL, bool NT = false>
 __global__ __launch_bounds__(TILE, (sizeof(T) == 8 ? 3 : 1))
 void k_bands(const T* __restrict__ tab, const T* __restrict__ cst, int64_t Bp, int64_t B, int chunk, MatPtrs<T> mat,
              T* __restrict__ bandsum) {
@@ -265,9 +266,9 @@ void k_bands(const T* __restrict__ tab, const T* __restrict__ cst, int64_t Bp, i
     // materialised spectra are stored as soon as they exist (leaf, then soil, then canopy) so that the store stream
     // is spread over the iteration instead of arriving as one burst of 9-11 stores at its end
     if (MAT && active) {
-      if (mat.leaf_refl) store_row(mat.leaf_refl, off_f, rho);
-      if (mat.leaf_tran) store_row(mat.leaf_tran, off_f, tau);
-      if (!thermal && mat.leaf_kchl) store_row(mat.leaf_kchl, off_o, (K > T(0)) ? divx(c[C_CAB] * tb.kab, K) : T(0));  // prospect_5d.py:197-198
+      if (mat.leaf_refl) store_row<NT>(mat.leaf_refl, off_f, rho);
+      if (mat.leaf_tran) store_row<NT>(mat.leaf_tran, off_f, tau);
+      if (!thermal && mat.leaf_kchl) store_row<NT>(mat.leaf_kchl, off_o, (K > T(0)) ? divx(c[C_CAB] * tb.kab, K) : T(0));  // prospect_5d.py:197-198
     }
     // order: leaf -> canopy solve for the leaf alone -> soil -> coupling with the soil background.  The soil model
     // sits between the two canopy parts because that schedule measured fastest (interleaved A/B of four orders).
@@ -278,8 +279,8 @@ void k_bands(const T* __restrict__ tab, const T* __restrict__ cst, int64_t Bp, i
     T rwet;
     soil_band<T>(tb, rdry, c[C_WET], fm, c[C_FMSUM], c[C_FILM2L], rwet);
     if (MAT && active) {
-      if (mat.soil_refl) store_row(mat.soil_refl, off_f, rwet);
-      if (!thermal && mat.soil_dry) store_row(mat.soil_dry, off_o, rdry);
+      if (mat.soil_refl) store_row<NT>(mat.soil_refl, off_f, rwet);
+      if (!thermal && mat.soil_dry) store_row<NT>(mat.soil_dry, off_o, rdry);
     }
     T rso, rdo, rsd, rdd;
     canopy_soil<T>(cp, core, rwet, rso, rdo, rsd, rdd);
@@ -290,10 +291,10 @@ void k_bands(const T* __restrict__ tab, const T* __restrict__ cst, int64_t Bp, i
     }
     if (MAT) {
       if (active) {
-        if (mat.rso) store_row(mat.rso, off_f, rso);
-        if (mat.rdo) store_row(mat.rdo, off_f, rdo);
-        if (mat.rsd) store_row(mat.rsd, off_f, rsd);
-        if (mat.rdd) store_row(mat.rdd, off_f, rdd);
+        if (mat.rso) store_row<NT>(mat.rso, off_f, rso);
+        if (mat.rdo) store_row<NT>(mat.rdo, off_f, rdo);
+        if (mat.rsd) store_row<NT>(mat.rsd, off_f, rsd);
+        if (mat.rdd) store_row<NT>(mat.rdd, off_f, rdd);
       }
       // thermal padding (SPART.py:427-470): the wave that holds the thermal evaluation (band 2001) copies it over
       // bands 2002..2161 of the padded spectra -- 160 values per array, three coalesced stores per lane
@@ -415,7 +416,7 @@ __device__ __forceinline__ void for_samples_staged(const T* __restrict__ cst, in
 
 // ------------------------------------------------------------------------------------------
 // standalone PROSPECT-5D / PRO: (B,2001) spectra out
-template <typename T>
+template <typename T, bool NT>
 __global__ __launch_bounds__(TILE) void k_prospect(const T* __restrict__ tab, const T* __restrict__ cst, int64_t Bp, int64_t B,
                                                    int chunk, int po, T* __restrict__ o_refl,
                                                    T* __restrict__ o_tran, T* __restrict__ o_kchl) {
@@ -439,16 +440,16 @@ __global__ __launch_bounds__(TILE) void k_prospect(const T* __restrict__ tab, co
     leaf_band<T>(tb, c[C_CAB], c[C_CCA], c[C_CDM], c[C_CW], c[C_CS], c[C_CANT], c[C_CBC], c[C_PROT], c[C_NM1], refl,
                  tran, absb, K);
     if (active) {
-      if (o_refl) store_row(o_refl, off, refl);
-      if (o_tran) store_row(o_tran, off, tran);
-      if (o_kchl) store_row(o_kchl, off, (K > T(0)) ? divx(c[C_CAB] * tb.kab, K) : T(0));
+      if (o_refl) store_row<NT>(o_refl, off, refl);
+      if (o_tran) store_row<NT>(o_tran, off, tran);
+      if (o_kchl) store_row<NT>(o_kchl, off, (K > T(0)) ? divx(c[C_CAB] * tb.kab, K) : T(0));
     }
     off += (unsigned)po * (unsigned)sizeof(T);
   });
 }
 
 // standalone BSM: (B,2001) wet and dry soil spectra; optional user dry spectra (bsm.py:42-43)
-template <typename T>
+template <typename T, bool NT>
 __global__ __launch_bounds__(TILE) void k_bsm(const T* __restrict__ tab, const T* __restrict__ cst, int64_t Bp, int64_t B,
                                               int chunk, int po, const T* __restrict__ rdry_in,
                                               T* __restrict__ o_refl, T* __restrict__ o_dry) {
@@ -471,15 +472,15 @@ __global__ __launch_bounds__(TILE) void k_bsm(const T* __restrict__ tab, const T
     T rwet;
     soil_band<T>(tb, rdry, c[C_WET], fm, c[C_FMSUM], c[C_FILM2L], rwet);
     if (active) {
-      if (o_refl) store_row(o_refl, off, rwet);
-      if (o_dry) store_row(o_dry, off, rdry);
+      if (o_refl) store_row<NT>(o_refl, off, rwet);
+      if (o_dry) store_row<NT>(o_dry, off, rdry);
     }
     off += (unsigned)po * (unsigned)sizeof(T);
   });
 }
 
 // standalone SAILH: leaf / soil spectra in, four canopy reflectance spectra out, all (B,2162)
-template <typename T>
+template <typename T, bool NT>
 __global__ __launch_bounds__(TILE) void k_sailh(const T* __restrict__ cst, int64_t Bp, int64_t B, int chunk, int pf,
                                                 const T* __restrict__ i_rho, const T* __restrict__ i_tau,
                                                 const T* __restrict__ i_rs, T* __restrict__ o_rso,
@@ -503,7 +504,7 @@ __global__ __launch_bounds__(TILE) void k_sailh(const T* __restrict__ cst, int64
     T rso, rdo, rsd, rdd;
     canopy_band<T>(cp, rho, tau, T(1) - rho - tau, rs, rso, rdo, rsd, rdd);
     if (active) {
-      store_row(o_rso, off, rso); store_row(o_rdo, off, rdo); store_row(o_rsd, off, rsd); store_row(o_rdd, off, rdd);
+      store_row<NT>(o_rso, off, rso); store_row<NT>(o_rdo, off, rdo); store_row<NT>(o_rsd, off, rsd); store_row<NT>(o_rdd, off, rdd);
     }
     off += (unsigned)pf * (unsigned)sizeof(T);
   });
