@@ -15,10 +15,11 @@ from spart_amd import workloads  # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8_000_000
 P = workloads.lhs_params(B, "full")
 chunk = 1 << 20
-spart_amd.generate_lut(P[:chunk], "Sentinel2A-MSI", chunk=chunk)
+spart_amd.generate_lut(P[:chunk], "Sentinel2A-MSI", chunk=chunk, prune=False)
 torch.cuda.synchronize()
-for kw in (dict(fault_threads=0), dict(fault_threads=4), dict(fault_threads=8), dict(fault_threads=12),
-           dict(fault_threads=8, prune=True), dict(fault_threads=0, prune=True)):
+# prune=False: all 2162 bands of every spectrum evaluated (the function's default is the pruned column path)
+for kw in (dict(fault_threads=0, prune=False), dict(fault_threads=4, prune=False), dict(fault_threads=8, prune=False),
+           dict(fault_threads=12, prune=False), dict(fault_threads=8, prune=True), dict(fault_threads=0, prune=True)):
     best = 1e9
     for _ in range(2):
         t0 = time.perf_counter()
