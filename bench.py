@@ -531,8 +531,11 @@ def main():
                                        " + one RCCL gather of the (3, B/N, nb) block to rank 0 per step, overlapped with the next "
                                        "step's kernels") if world > 1 else "single GPU",
                        "input_dtype": "f64", "build_id": build_id,
-                       "columns": ("float32 full-band pass + float64 re-evaluation of the sensor-slot bands: columns = the float64 "
-                                   "mode's, rounded once") if args.dtype == "float32" else "float64 throughout",
+                       "columns": ("R_TOC / R_TOA / L_TOA come from the float64 column path (k_prelude -> k_slots -> k_sensor over the <= 2 nb "
+                                   "bands they depend on) in every mode: float32 columns = the float64 mode's, rounded once; the "
+                                   "full-band kernel k_bands (the dominant kernel of this step) evaluates all 2162 bands of every spectrum "
+                                   "beside it and feeds only the band sums -- roofline.columns_path_ms is what the returned columns "
+                                   "cost, configs.materialized the mode in which the band kernel's work is consumed"),
                        "tables": "17 table values per band held in VGPRs (lane = band); the per-sample constants, not the tables, "
                                  "are staged through LDS (north_star says tables in LDS; measured slower, DESIGN.md section 4)",
                        "finite": ok, "columns_checksum": checksum},
@@ -540,7 +543,9 @@ def main():
         }
         line["cpu_baseline"] = cpu
         if world == 1 and "columns_beside_bands" in line["roofline"]["stage_ms"]:
-            line["roofline"]["stage_ms_serial"] = serial_stages(torch, args.sensor, dev_index, P, args.dtype)
+            ser = serial_stages(torch, args.sensor, dev_index, P, args.dtype)
+            line["roofline"]["stage_ms_serial"] = ser
+            line["roofline"]["columns_path_ms"] = ser["prelude"] + ser["slots"] + ser["sensor"]
         if world == 1 and not args.no_extras and args.dtype == "float32":
             line["fp64"], line["configs"] = extras(torch, args, dev)
         print(json.dumps(line), flush=True)
