@@ -335,6 +335,8 @@ def mode_records(torch, args, dev):
     r["columns_bit_identical_to_full_evaluation"] = all(bool(torch.equal(full[k], pr[k])) for k in full)
     r["workload"] = (f"prune_unused_bands = 1: prelude + float64 sensor-slot pass ({eng.nb} of 2162 bands) + SMAC / TOC->TOA, 1M spectra, "
                      f"{args.sensor}; NOT full spectra -- reported as the cost of the returned columns, never as the headline")
+    rf = run_config(torch, eng, Pd, "float32", 20, 3, prune=True, lidf="newton")
+    r["with_fast_prelude"] = {"value": rf["value"], "ms_per_step": rf["ms_per_step"], "stage_ms": rf["stage_ms"]}
     rec["pruned"] = r
     # --- fast_prelude (lidf="newton"): the documented speed / agreement trade of the per-sample prelude, full evaluation
     fp = run_config(torch, eng, Pd, "float32", 10, 2, lidf="newton")

@@ -35,6 +35,7 @@ def main():
     ref = None
     band = {n: [] for n in engs}
     wall = {n: [] for n in engs}
+    pre = {n: [] for n in engs}
     dev = {}
     for n, e in engs.items():
         o = e.run(P, a.dtype, prune=a.prune)
@@ -43,19 +44,37 @@ def main():
         if ref is None:
             ref = cur
         dev[n] = ((cur - ref).abs() / ref.abs().clamp_min(1e-3)).max().item()
+    import random
+    random.seed(1)
     for _ in range(a.rounds):
-        for n, e in engs.items():
+        order = list(engs.items())
+        random.shuffle(order)                     # (position in the round matters: clocks / thermal state)
+        for n, e in order:
             e.profile(1)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             e.run(P, a.dtype, prune=a.prune)
             torch.cuda.synchronize()
             wall[n].append((time.perf_counter() - t0) * 1e3)
-            ms, _ = e.profile_read()
-            band[n].append(ms)
+            st, _ = e.profile_read_stages()
+            band[n].append(st["bands"])
+            pre[n].append(st["prelude"])
             e.profile(0)
+    # the column kernels' own durations: a second context per build with every kernel on one stream
+    os.environ["SPART_SIDE_STREAM"] = "0"
+    ser = {}
+    for b in a.builds:
+        name, path = b.split("=", 1)
+        e = Engine(a.sensor, 0, lib_path=path)
+        e.run(P, a.dtype, prune=a.prune)
+        e.profile(5)
+        for _ in range(5):
+            e.run(P, a.dtype, prune=a.prune)
+        st, k = e.profile_read_stages()
+        e.profile(0)
+        ser[name] = {q: v / k for q, v in st.items()}
     for n in engs:
-        print(f"{n:24s} band min {min(band[n]):8.3f} med {statistics.median(band[n]):8.3f} ms | "
+        print(f"{n:24s} serial slots {ser[n]['slots']:.3f} sensor {ser[n]['sensor']:.3f} | prelude min {min(pre[n]):6.3f} | band min {min(band[n]):8.3f} med {statistics.median(band[n]):8.3f} ms | "
               f"step min {min(wall[n]):8.3f} med {statistics.median(wall[n]):8.3f} ms | dev vs first {dev[n]:.2e}", flush=True)
 
 
