@@ -56,3 +56,20 @@ def test_null_context_errors_do_not_need_a_gpu(lib_path):
     assert lib.spart_workspace_bytes(None, 0, ctypes.c_int64(10)) == 0
     rc = lib.spart_ctx_create(None, 0, None)
     assert rc == -1 and b"null" in lib.spart_last_error(None)
+
+
+def test_build_id_ties_the_binary_to_its_sources(lib_path, tmp_path):
+    """spart_build_id() == the hash of the sources / flags next to the library (build.source_id), read both from the loaded
+    code and from the file's bytes; a file without (or with another) id is detected without loading it."""
+    import build
+    lib = ctypes.CDLL(lib_path)
+    lib.spart_build_id.restype = ctypes.c_char_p
+    want = build.source_id(True)
+    assert lib.spart_build_id().decode() == want and build.binary_id(lib_path) == want and len(want) == 12
+    assert not build.needs_build(True)
+    fake = tmp_path / "lib.so"
+    fake.write_bytes(b"\x7fELF....SPART_BUILD_ID:0123456789ab....")
+    assert build.binary_id(str(fake)) == "0123456789ab" != want
+    fake.write_bytes(b"\x7fELF no id here")
+    assert build.binary_id(str(fake)) is None and build.binary_id(str(tmp_path / "missing.so")) is None
+    assert build.source_id(False) != want and build.source_id(True, ["-DX=1"]) != want      # flags are part of the id

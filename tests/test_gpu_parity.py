@@ -759,6 +759,26 @@ def test_lut_inversion_matches_brute_force(dtype, nb, torch_mod):
             assert list(idx[:5]) == [100, 101, 102, 103, 104] and np.all(cost[:5] == 0.0)
 
 
+def test_caller_owned_spectrum_buffers(torch_mod):
+    """Engine.run(out=...) with caller-owned materialise buffers (the C ABI's ownership rule: the caller owns every buffer):
+    results land in the given tensors, a second call reuses them, and a buffer with the wrong layout is refused."""
+    from spart_amd import get_engine, workloads
+    eng = get_engine("Sentinel2A-MSI", 0)
+    P = torch_mod.as_tensor(workloads.lhs_params(300, "full", seed=2).T.copy(), device="cuda:0")
+    fields = ("rso", "leaf_kchl", "rsoil")
+    first = eng.run(P, "float32", materialize=fields)
+    keep = {k: first[k].clone() for k in first}
+    for v in first.values():
+        v.zero_()
+    again = eng.run(P, "float32", materialize=fields, out=first)
+    for k in keep:
+        assert again[k].data_ptr() == first[k].data_ptr() and torch_mod.equal(again[k], keep[k]), k
+    with pytest.raises(ValueError, match="row stride"):
+        eng.run(P, "float32", materialize=("rso",), out={"rso": torch_mod.empty((300, 2162), dtype=torch_mod.float32, device="cuda:0")})
+    with pytest.raises(ValueError):
+        eng.run(P, "float32", materialize=("rsoil",), out={"rsoil": torch_mod.empty((300, 12), dtype=torch_mod.float32, device="cuda:0")})
+
+
 def test_fast_prelude_option_stays_inside_the_contract(golden, torch_mod):
     """Engine.run(lidf="newton") = spart_materialize.fast_prelude: the exact root of the LIDF equation (the reference stops its
     iteration up to ~5e-8 short, sailh.py:378-382) and 8-point hot-spot panels.  Against the REFERENCE's golden rows the
