@@ -44,7 +44,7 @@ def _prefault(a):
         return False
 
 
-def generate_lut(params, sensor, path=None, dtype="float32", chunk=1 << 20, device=None, prune=True, fault_threads=8,
+def generate_lut(params, sensor, path=None, dtype="float32", chunk=1 << 18, device=None, prune=True, fault_threads=8,
                  f32_bands=False):
     """params: (B, 27) array-like on the HOST (numpy / memmap).  Returns dict of host arrays (np.memmap when
     ``path`` is given).  ``prune=True`` (default: a LUT holds the sensor columns only) evaluates just the <= 2 nb bands those columns
@@ -58,6 +58,9 @@ def generate_lut(params, sensor, path=None, dtype="float32", chunk=1 << 20, devi
         download(i)   D2H of the three (n, nb) column blocks straight into the destination arrays / memmaps
                                                                             -- overlaps the kernels of chunk i+1
         prefault(i+2) ``fault_threads`` helper threads make the destination pages of chunk i+2 resident (see _prefault)
+    ``chunk`` = 262 144 rows by default: the pipeline's fill (first upload) and drain (last download) are not overlapped
+    with anything, so smaller chunks waste less (8M spectra, all bands: 112 ms with 1M-row chunks, 105 ms with 256k; below
+    that the per-chunk launch / copy overheads win).
     The copies block the HOST thread (pageable memory) but not the GPU, which stays busy as long as the two copies
     of a chunk (372 B per spectrum, ~7 ms per 1M at PCIe Gen5 rates) take less than its kernels (12 ms per 1M)."""
     import warnings
