@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/spart_hip.h"
+#include "spart_bands_f32.h"
 #include "spart_kernels.h"
 
 using namespace spart;
@@ -357,20 +358,22 @@ static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_
     return SPART_OK;
   };
   auto band_kernels = [&]() -> int {           // the full-band kernel (+ the batch-mean reduction), on the caller's stream
-#define SPART_LAUNCH_BANDS(M, F)                                                                                          \
-  do {                                                                                                                    \
-    if ((M) != 0 && nt) hipLaunchKernelGGL((k_bands<T, M, F, (M) != 0>), grid, dim3(TILE), 0, st, tab, cst, Bp, B, chunk, mp, bsum); \
-    else hipLaunchKernelGGL((k_bands<T, M, F, false>), grid, dim3(TILE), 0, st, tab, cst, Bp, B, chunk, mp, bsum);        \
-  } while (0)
-    if (mat && mp.rdry_in && full && four) SPART_LAUNCH_BANDS(2, 2);
-    else if (mat && mp.rdry_in && full) SPART_LAUNCH_BANDS(2, 1);
-    else if (mat && mp.rdry_in) SPART_LAUNCH_BANDS(2, 0);
-    else if (mat && full && four) SPART_LAUNCH_BANDS(1, 2);
-    else if (mat && full) SPART_LAUNCH_BANDS(1, 1);
-    else if (mat) SPART_LAUNCH_BANDS(1, 0);
-    else if (full && four) SPART_LAUNCH_BANDS(0, 2);
-    else if (full) SPART_LAUNCH_BANDS(0, 1);
-#undef SPART_LAUNCH_BANDS
+    const int M = mat ? (mp.rdry_in ? 2 : 1) : 0;
+    const int F = !full ? 0 : (four ? 2 : 1);
+#define SPART_CASE(MM, FF)                                                                                                      \
+  if (M == (MM) && F == (FF)) {                                                                                                 \
+    if ((MM) != 0 && nt) hipLaunchKernelGGL((k_bands<T, MM, FF, (MM) != 0>), grid, dim3(TILE), 0, st, tab, cst, Bp, B, chunk, mp, bsum); \
+    else hipLaunchKernelGGL((k_bands<T, MM, FF, false>), grid, dim3(TILE), 0, st, tab, cst, Bp, B, chunk, mp, bsum);            \
+  }
+    if constexpr (sizeof(T) == 4) {
+      // the float32 kernels WITHOUT materialised spectra (the headline's dominant kernel) are compiled in their own
+      // translation unit with their own scheduling strategy (spart_bands_f32.hip, build.py: TU_FLAGS)
+      if (M == 0) HIP_TRY(ctx, launch_bands_f32(F, grid.x, st, (const float*)tab, (const float*)cst, Bp, B, chunk, (float*)bsum));
+    } else {
+      SPART_CASE(0, 1) SPART_CASE(0, 2)
+    }
+    SPART_CASE(1, 0) SPART_CASE(1, 1) SPART_CASE(1, 2) SPART_CASE(2, 0) SPART_CASE(2, 1) SPART_CASE(2, 2)
+#undef SPART_CASE
     HIP_TRY(ctx, hipGetLastError());
     if (prof) HIP_TRY(ctx, hipEventRecord(ev[2], st));
     if (opt && opt->band_mean) {

@@ -13,6 +13,7 @@
 
 namespace spart {
 
+// (Kernels that are not templates are `static`: this header is included by two translation units.)
 constexpr int TILE = 256;                 // lanes (= bands) per workgroup
 constexpr int NTILE = 8;                  // 8 * 256 = 2048 >= NEVAL
 constexpr int NTILE_FULL = 9;             // 9 * 256 >= 2162 (standalone SAILH: arbitrary thermal inputs)
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(256, SPART_PRELUDE_WAVES) void k_prelude(ParamPtrs 
 }
 
 // leaf-angle distribution only (CanopyStructure.lidf, sailh.py:348)
-__global__ __launch_bounds__(256) void k_lidf(const double* __restrict__ a, const double* __restrict__ b, int64_t B,
+static __global__ __launch_bounds__(256) void k_lidf(const double* __restrict__ a, const double* __restrict__ b, int64_t B,
                                               double* __restrict__ lidf) {
   int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= B) return;
@@ -596,7 +597,7 @@ __global__ __launch_bounds__(1024) void k_sensor(SensorTab st, const TG* __restr
 struct Out9 {
   double* o[9];
 };
-__global__ __launch_bounds__(256) void k_smac(const double* __restrict__ coef, int nb, const double* __restrict__ atm,
+static __global__ __launch_bounds__(256) void k_smac(const double* __restrict__ coef, int nb, const double* __restrict__ atm,
                                               int64_t Bp, int64_t B, Out9 out) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * nb) return;
@@ -614,7 +615,7 @@ __global__ __launch_bounds__(256) void k_smac(const double* __restrict__ coef, i
 // Context-creation kernel: SRF convolution of the extraterrestrial irradiance
 // (calculate_spectral_convolution, SPART.py:358-396).  One wave per sensor band; lanes stride
 // over the SRF samples, then a 64-lane shuffle reduction of sum(Ea[idx] p) and sum(p).
-__global__ __launch_bounds__(64) void k_econv(const double* __restrict__ Ea, const double* __restrict__ wl_srf,
+static __global__ __launch_bounds__(64) void k_econv(const double* __restrict__ Ea, const double* __restrict__ wl_srf,
                                               const double* __restrict__ p_srf, int nsrf, int nb,
                                               double* __restrict__ econv) {
   const int b = blockIdx.x;
@@ -812,7 +813,7 @@ __global__ __launch_bounds__(256, 2) void k_lut_scan_mfma(const float* __restric
 // minimum over the (slice, half) partial results, then the row inside the winning 32-row tile by the directly
 // evaluated cost sum_j w_j (x_j - y_j)^2 (which is also the cost that is reported): ascending + strict '<' = ties to
 // the lowest row index
-__global__ __launch_bounds__(256) void k_lut_reduce_tiles(const float* __restrict__ part_cost, const int* __restrict__ part_tile,
+static __global__ __launch_bounds__(256) void k_lut_reduce_tiles(const float* __restrict__ part_cost, const int* __restrict__ part_tile,
                                                           const float* __restrict__ lut, const float* __restrict__ obs,
                                                           const float* __restrict__ w, int nb, int64_t B, int64_t M, int npart,
                                                           int64_t* __restrict__ best_idx, float* __restrict__ best_cost) {

@@ -144,6 +144,8 @@ template <> struct Mx<float> {
 };
 
 #if defined(__HIPCC__)
+// (Device tables in this header are `static`: the library is built from more than one translation unit -- the float32
+// full-band kernels are compiled on their own, spart_bands_f32.hip -- and each unit carries its own copy.)
 // Coefficient tables in constant memory are read through a pointer the optimiser cannot prove loop-invariant
 // (SPART_FRESH): left alone, hipcc hoists all 48 float64 coefficients of the band path (96 SGPRs) out of the sample
 // loop, runs out of SGPRs and parks them in VGPR lanes -- 32 v_readlane / v_writelane per band and sample in
@@ -190,11 +192,11 @@ __device__ __forceinline__ double spart_horner(double p, double x, double c_unif
 //    propagates a NaN argument by itself: in leaf_band / soil_band / canopy_core every result of exp / log is multiplied
 //    with terms that are NaN when the argument is (test_nan_and_nonphysical_inputs_do_not_crash).  Relative error <= 3e-16 (exp), absolute <= 3e-16 / relative <= 2e-15 away from
 //    x = 1 (log).
-__device__ __constant__ double c_EXP_F64[12] = {1.0 / 2, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320,
+static __device__ __constant__ double c_EXP_F64[12] = {1.0 / 2, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320,
                                                 1.0 / 362880, 1.0 / 3628800, 1.0 / 39916800, 1.0 / 479001600, 1.0 / 6227020800.0};
 #if defined(__HIP_DEVICE_COMPILE__)
-__device__ const double g_F64_EXP_TAB[F64_EXP_TAB] = SPART_F64_EXP_TABLE;
-__device__ const double g_F64_LOG_TAB[2 * F64_LOG_TAB] = SPART_F64_LOG_TABLE;
+static __device__ const double g_F64_EXP_TAB[F64_EXP_TAB] = SPART_F64_EXP_TABLE;
+static __device__ const double g_F64_LOG_TAB[2 * F64_LOG_TAB] = SPART_F64_LOG_TABLE;
 __shared__ __attribute__((aligned(16))) double s_f64_exp_tab[F64_EXP_TAB];
 __shared__ __attribute__((aligned(16))) double s_f64_log_tab[2 * F64_LOG_TAB];
 // all threads of the workgroup; ends with a barrier
@@ -422,10 +424,10 @@ template <> struct E3c<float> {
 static_assert(E3_G_DEG_F64 == 12 && E3_W_DEG_F64 == 6, "tables below list the coefficients one by one");
 #define SPART_L13(a) {a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], a[10], a[11], a[12]}
 #define SPART_L7(a) {a[0], a[1], a[2], a[3], a[4], a[5], a[6]}
-__device__ __constant__ double c_E3_G_F64[13] = SPART_L13(E3_G_F64);
+static __device__ __constant__ double c_E3_G_F64[13] = SPART_L13(E3_G_F64);
 #define SPART_L7X2(a) {2 * a[0], 2 * a[1], 2 * a[2], 2 * a[3], 2 * a[4], 2 * a[5], 2 * a[6]}
-__device__ __constant__ double c_E3_P_F64[7] = SPART_L7X2(E3_P_F64);   // 2 P: the factor 2 of tau = 2 E3 folded in (exact)
-__device__ __constant__ double c_E3_Q_F64[7] = SPART_L7(E3_Q_F64);
+static __device__ __constant__ double c_E3_P_F64[7] = SPART_L7X2(E3_P_F64);   // 2 P: the factor 2 of tau = 2 E3 folded in (exact)
+static __device__ __constant__ double c_E3_Q_F64[7] = SPART_L7(E3_Q_F64);
 #endif
 template <> struct E3c<double> {
   static constexpr int GD = E3_G_DEG_F64, WD = E3_W_DEG_F64;

@@ -11,7 +11,6 @@ import subprocess
 import pytest
 
 ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-SRC = os.path.join(ROOT, "spart-python_amd", "csrc", "spart_capi.hip")
 
 
 def _hipcc():
@@ -26,11 +25,11 @@ def kernel_meta(tmp_path_factory):
     cc = _hipcc()
     if cc is None:
         pytest.skip("hipcc not available")
-    out = tmp_path_factory.mktemp("isa") / "capi.s"
-    subprocess.check_call([cc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-slp-vectorize", "-DSPART_FAST_MATH=1",
-                           "-S", "--cuda-device-only", "-o", str(out), SRC], stderr=subprocess.DEVNULL)
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "spart-python_amd"))
+    import build                      # every translation unit with ITS flags (build.TU_FLAGS)
     meta, cur = {}, None
-    for line in open(out):
+    for line in (l for f in build.device_asm(str(tmp_path_factory.mktemp("isa"))) for l in open(f)):
         m = re.match(r"\s+\.name:\s+(\S+)", line)
         if m:
             cur = m.group(1)

@@ -13,7 +13,7 @@ for f in files:
     open(os.path.join(tmp, f), "wb").write(data)
 sys.path.insert(0, os.path.join(ROOT, "spart-python_amd"))
 import build
-cmd = [build.hipcc(), *build.FLAGS, "-DSPART_FAST_MATH=1", "-o", out, os.path.join(tmp, "spart-python_amd", "csrc", "spart_capi.hip")]
-subprocess.check_call(cmd)
+build.SOURCES = [os.path.join(tmp, "spart-python_amd", "csrc", os.path.basename(s)) for s in build.SOURCES]   # both translation units
+build._compile_and_link(out, ["-DSPART_FAST_MATH=1", f'-DSPART_BUILD_ID="rev-{rev[:8]}"'], (), True)
 shutil.rmtree(tmp)
 print(out)

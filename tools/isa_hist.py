@@ -9,13 +9,11 @@ import sys
 import tempfile
 
 ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-SRC = os.path.join(ROOT, "spart-python_amd", "csrc", "spart_capi.hip")
+sys.path.insert(0, os.path.join(ROOT, "spart-python_amd"))
+import build  # noqa: E402
 frag = sys.argv[1]
 with tempfile.TemporaryDirectory() as d:
-    out = os.path.join(d, "capi.s")
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-slp-vectorize",
-                           "-DSPART_FAST_MATH=1", "-S", "--cuda-device-only", "-o", out, SRC, *sys.argv[2:]], stderr=subprocess.DEVNULL)
-    lines = open(out).read().split("\n")
+    lines = [l for f in build.device_asm(d, sys.argv[2:]) for l in open(f).read().split("\n")]   # all translation units
 start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN5spart.*:", l) and frag in l)
 end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm"))
 body = [l.strip() for l in lines[start + 1:end]]

@@ -8,17 +8,14 @@ import sys
 import tempfile
 
 ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-SRC = os.path.join(ROOT, "spart-python_amd", "csrc", "spart_capi.hip")
+sys.path.insert(0, os.path.join(ROOT, "spart-python_amd"))
+import build  # noqa: E402
 
 
 def kernel_meta(extra=()):
     with tempfile.TemporaryDirectory() as d:
-        out = os.path.join(d, "capi.s")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-slp-vectorize",
-                               "-DSPART_FAST_MATH=1", "-S", "--cuda-device-only", "-o", out, SRC, *extra],
-                              stderr=subprocess.DEVNULL)
         meta, cur = {}, None
-        for line in open(out):
+        for line in (l for f in build.device_asm(d, extra) for l in open(f)):     # every translation unit, with ITS flags
             m = re.match(r"\s+\.name:\s+(\S+)", line)
             if m:
                 cur = m.group(1)
