@@ -130,7 +130,7 @@ def roofline(dtype, B, nb, stage_ms, step_ms, band_kernel):
     c, source, fresh = counters(dtype)
     if c is not None and B == c.get("batch") and nb == c.get("nb"):
         k = c["kernels"]
-        key = band_kernel.replace(" ", "").rstrip(">")          # (round-2 profiles carry a fourth template argument)
+        key = ",".join(band_kernel.replace(" ", "").rstrip(">").split(",")[:3])     # (older profiles: other trailing template arguments)
         bk = next((v for n, v in k.items() if n.replace(" ", "").startswith(key)), None)
         if bk and "SQ_INSTS_VALU" in bk:
             r["issue"] = {"valu_wave_insts_per_launch": bk["SQ_INSTS_VALU"],
@@ -221,7 +221,7 @@ def extras(torch, args, dev):
     eng = get_engine(args.sensor, dev.index)
     P = torch.as_tensor(workloads.lhs_params(args.batch, "full").T.copy(), device=dev)
     r = run_config(torch, eng, P, "float64", steps, 1)
-    r["roofline"] = roofline("float64", args.batch, eng.nb, r["stage_ms"], r["ms_per_step"], "k_bands<double, 0, 1>")
+    r["roofline"] = roofline("float64", args.batch, eng.nb, r["stage_ms"], r["ms_per_step"], "k_bands<double, 0, 1, false>")
     r["dtype"] = "f64"
     # float64 columns over a float32 full-band pass (spart_materialize.f32_bands): the SAME float64 columns -- checked
     # here bit for bit -- at the float32 mode's speed; the 2162 bands of every sample are still all evaluated, in float32
@@ -315,7 +315,7 @@ def mode_records(torch, args, dev):
         "bytes_per_spectrum": MAT_BYTES_F32 + algorithmic_bytes(eng.nb, "float32"),
         "step_GBps": (nbytes + algorithmic_bytes(eng.nb, "float32") * B) / sec / 1e9,
         "finite": all(bool(torch.isfinite(out[k]).all().item()) for k in MAT_FIELDS),
-        "roofline": {"bound": "hbm", "kernel": "k_bands<float, 1, 1>", "kernel_ms": kms,
+        "roofline": {"bound": "hbm", "kernel": "k_bands<float, 1, 1, true>", "kernel_ms": kms,
                      "achieved": nbytes / (kms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": nbytes / (kms / 1e3) / 1e9 / HBM_PEAK_GBS, "frac_over_step": nbytes / sec / 1e9 / HBM_PEAK_GBS,
                      "algorithmic_bytes_per_launch": nbytes, "traffic": traffic,
@@ -519,7 +519,7 @@ def main():
         checksum = int(sum(int(g.view(bits).to(torch.int64).sum().item()) for g in blocks) & ((1 << 63) - 1))
         value = Bg * args.steps / dt
         stage_ms = {k: v / max(ncalls, 1) for k, v in stage.items()}
-        band_kernel = "k_bands<float, 0, 1>" if args.dtype == "float32" else "k_bands<double, 0, 1>"
+        band_kernel = "k_bands<float, 0, 1, false>" if args.dtype == "float32" else "k_bands<double, 0, 1, false>"
         line = {
             "metric": METRIC,
             "value": value, "unit": "spectra/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -135,7 +135,7 @@ def test_bench_finds_its_committed_profile_numbers():
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    for dtype, kernel, ms in (("float32", "k_bands<float, 0, 1>", 10.2), ("float64", "k_bands<double, 0, 1>", 29.0)):
+    for dtype, kernel, ms in (("float32", "k_bands<float, 0, 1, false>", 10.2), ("float64", "k_bands<double, 0, 1, false>", 29.0)):
         stage = {"prelude": 1.0, "bands": ms, "slots": 0.3, "sensor": 0.3}
         r = bench.roofline(dtype, 1_000_000, 13, stage, sum(stage.values()), kernel)
         assert r["bound"] == "valu" and 0.3 < r["frac"] < 1.0
