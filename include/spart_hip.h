@@ -178,10 +178,13 @@ int spart_run_batch(spart_ctx *ctx, int dtype, int64_t B, const double *const pa
 /* LUT inversion (the use LUTs are generated for -- no counterpart in the reference):
  * for each of M observed sensor spectra obs (M,nb) find the row of lut (B,nb) that minimises
  * sum_j w_j (lut[b,j] - obs[m,j])^2 (weights (nb,) optional, NULL = 1).  best_idx (M,) int64, best_cost (M,) =
- * that minimum (divide by nb and take the root for an RMSE), recomputed directly from the winning row; ties go to
- * the lowest row index; NaN rows never win.  In float32 the RANKING evaluates |x|^2 - 2 x.y, i.e. rows whose distances
- * to an observation differ by less than ~1e-7 |y|^2 may swap (use SPART_F64 for radiance-scale columns).  All pointers
- * are device memory in `dtype`; nb <= 31. */
+ * that minimum (divide by nb and take the root for an RMSE), evaluated directly from the winning row; ties go to
+ * the lowest row index; NaN rows never win (-1 / +inf when no row has a finite cost).
+ * The search is a GEMM with K = nb + 1 on the matrix cores -- exact-f32 v_mfma_f32_32x32x2_f32 (bitwise an fmaf chain) for
+ * SPART_F32, v_mfma_f64_16x16x4_f64 for SPART_F64 -- which RANKS the tiles of 32 / 16 LUT rows by |x|^2 - 2 x.y; inside the
+ * winning tile the row is picked by the directly evaluated cost.  In float32, tiles whose best distances to an observation
+ * differ by less than ~1e-7 |y|^2 may therefore swap (use SPART_F64 for radiance-scale columns or single-band LUTs).
+ * All pointers are device memory in `dtype`; nb <= 31. */
 size_t spart_lut_workspace_bytes(int dtype, int64_t B, int nb, int64_t M);
 int spart_lut_nearest(spart_ctx *ctx, int dtype, int64_t B, int nb, const void *lut, int64_t M, const void *obs,
                       const void *weights, int64_t *best_idx, void *best_cost, void *workspace, size_t workspace_bytes,

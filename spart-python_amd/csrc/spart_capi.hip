@@ -408,40 +408,47 @@ static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_
   return SPART_OK;
 }
 
-// LUT inversion: number of row slices so that (M/256) x nslice workgroups fill 256 CUs several times over
-static int lut_slices(int64_t M) {
-  int64_t mb = (M + 255) / 256;
-  int64_t n = (4096 + mb - 1) / mb;
-  if (n < 1) n = 1;
+// float64: the same GEMM + argmin on v_mfma_f64_16x16x4_f64 (k_lut_scan_mfma64): K steps of 4, 16-row tiles
+static int lut_ks64(int nb) {
+  const int need = (nb + 4) / 4;                      // ceil((nb + 1) / 4)
+  for (int ks : {2, 4, 6, 8})
+    if (ks >= need) return ks;
+  return 8;
+}
+static int lut_to64(int ks) { return ks <= 4 ? 8 : 4; }     // 16-observation blocks per wave (operand registers: 2 KS TO)
+static int lut_slices_mfma64(int64_t M, int64_t ntile, int to) {
+  const int64_t mg = (M + 16 * to * 4 - 1) / (16 * to * 4);
+  int64_t n = (4096 + mg - 1) / mg;
+  if (n > ntile) n = ntile;
   if (n > 1024) n = 1024;
+  if (n < 1) n = 1;
   return (int)n;
 }
-
-static int lut_nbp(int nb) { return nb <= 15 ? 16 : 32; }
-
-// float64: vector-ALU scan (k_lut_scan), one observation per lane
 static int lut_impl_f64(spart_ctx* ctx, int64_t B, int nb, const void* lut, int64_t M, const void* obs, const void* weights,
                         int64_t* best_idx, void* best_cost, char* wsp, hipStream_t st) {
-  using T = double;
-  const int nslice = lut_slices(M);
-  const int nbp = lut_nbp(nb);
-  T* padded = (T*)wsp;
-  T* pc = (T*)(wsp + align_up((size_t)B * nbp * sizeof(T)));
-  int64_t* pi = (int64_t*)((char*)pc + align_up((size_t)nslice * M * sizeof(T)));
-  dim3 gprep((unsigned)((B + 255) / 256));
-  dim3 grid((unsigned)((M + 255) / 256), (unsigned)nslice);
-  if (nbp == 16) {
-    hipLaunchKernelGGL((k_lut_prep<T, 16>), gprep, dim3(256), 0, st, (const T*)lut, (const T*)weights, nb, B, padded);
-    hipLaunchKernelGGL((k_lut_scan<T, 16>), grid, dim3(256), 0, st, (const T*)padded, (const T*)obs, (const T*)weights,
-                       nb, B, M, nslice, pc, pi);
-  } else {
-    hipLaunchKernelGGL((k_lut_prep<T, 32>), gprep, dim3(256), 0, st, (const T*)lut, (const T*)weights, nb, B, padded);
-    hipLaunchKernelGGL((k_lut_scan<T, 32>), grid, dim3(256), 0, st, (const T*)padded, (const T*)obs, (const T*)weights,
-                       nb, B, M, nslice, pc, pi);
+  const int ks = lut_ks64(nb), to = lut_to64(ks);
+  const int64_t ntile = (B + 15) / 16;
+  const int nslice = lut_slices_mfma64(M, ntile, to);
+  double* tiles = (double*)wsp;
+  double* pc = (double*)(wsp + align_up((size_t)ntile * ks * 64 * 8));
+  int* pt = (int*)((char*)pc + align_up((size_t)nslice * 4 * M * 8));
+  const dim3 gprep((unsigned)((ntile * ks * 64 + 255) / 256));
+  const dim3 grid((unsigned)((M + 16 * to * 4 - 1) / (16 * to * 4)), (unsigned)nslice);
+#define SPART_LUT_KS(K, TO)                                                                                                 \
+  case K:                                                                                                                    \
+    hipLaunchKernelGGL((k_lut_prep_mfma64<K>), gprep, dim3(256), 0, st, (const double*)lut, (const double*)weights, nb, B,   \
+                       ntile, tiles);                                                                                        \
+    hipLaunchKernelGGL((k_lut_scan_mfma64<K, TO>), grid, dim3(256), 0, st, (const double*)tiles, (const double*)obs,         \
+                       (const double*)weights, nb, ntile, M, nslice, pc, pt);                                                \
+    break;
+  switch (ks) {
+    SPART_LUT_KS(2, 8) SPART_LUT_KS(4, 8) SPART_LUT_KS(6, 4) SPART_LUT_KS(8, 4)
   }
+#undef SPART_LUT_KS
   HIP_TRY(ctx, hipGetLastError());
-  hipLaunchKernelGGL((k_lut_reduce<T>), dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, (const T*)pc, (const int64_t*)pi,
-                     (const T*)lut, (const T*)obs, (const T*)weights, nb, M, nslice, best_idx, (T*)best_cost);
+  hipLaunchKernelGGL((k_lut_reduce_tiles<double, 16>), dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, (const double*)pc,
+                     (const int*)pt, (const double*)lut, (const double*)obs, (const double*)weights, nb, B, M, 4 * nslice,
+                     best_idx, (double*)best_cost);
   HIP_TRY(ctx, hipGetLastError());
   return SPART_OK;
 }
@@ -485,7 +492,7 @@ static int lut_impl_f32(spart_ctx* ctx, int64_t B, int nb, const void* lut, int6
   }
 #undef SPART_LUT_KS
   HIP_TRY(ctx, hipGetLastError());
-  hipLaunchKernelGGL(k_lut_reduce_tiles, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, (const float*)pc, (const int*)pt,
+  hipLaunchKernelGGL((k_lut_reduce_tiles<float, 32>), dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, (const float*)pc, (const int*)pt,
                      (const float*)lut, (const float*)obs, (const float*)weights, nb, B, M, 2 * nslice, best_idx, (float*)best_cost);
   HIP_TRY(ctx, hipGetLastError());
   return SPART_OK;
@@ -833,8 +840,10 @@ size_t spart_lut_workspace_bytes(int dtype, int64_t B, int nb, int64_t M) {
     const int nslice = lut_slices_mfma(M, ntile);
     return align_up((size_t)ntile * lut_ks(nb) * 64 * 4) + 2 * align_up((size_t)nslice * 2 * M * 4);
   }
-  int nslice = lut_slices(M);
-  return align_up((size_t)B * lut_nbp(nb) * 8) + align_up((size_t)nslice * M * 8) + align_up((size_t)nslice * M * 8);
+  const int64_t ntile = (B + 15) / 16;
+  const int ks = lut_ks64(nb);
+  const int nslice = lut_slices_mfma64(M, ntile, lut_to64(ks));
+  return align_up((size_t)ntile * ks * 64 * 8) + align_up((size_t)nslice * 4 * M * 8) + align_up((size_t)nslice * 4 * M * 4);
 }
 
 int spart_lut_nearest(spart_ctx* ctx, int dtype, int64_t B, int nb, const void* lut, int64_t M, const void* obs,

@@ -646,59 +646,9 @@ static __global__ __launch_bounds__(64) void k_econv(const double* __restrict__ 
 // LUT inversion (no counterpart in the reference): for every observed spectrum find the LUT
 // row with the smallest weighted squared distance  sum_j w_j (x_bj - y_mj)^2.
 //   cost(b, m) = n_b + sum_j x_bj * (-2 w_j y_mj) + sum_j w_j y_mj^2,   n_b = sum_j w_j x_bj^2 (k_lut_norms)
-// Mapping: lane = observation (its -2 w y in VGPRs for the whole scan), LUT rows are wave-uniform and stream
-// through scalar loads; the LUT is cut into `nslice` row ranges so that M/256 x nslice workgroups fill the chip;
-// k_lut_reduce takes the minimum over slices.  NaN rows never win (comparisons with NaN are false).
-// pre-pass: rows re-laid out as NBP (16 or 32) values, NBP*sizeof(T)-aligned, so that one s_load_dwordx16
-// (x32) fetches a whole row: [x_0 .. x_{nb-1}, 0 .., n_b] with the weighted norm n_b in the last slot
-template <typename T, int NBP>
-__global__ __launch_bounds__(256) void k_lut_prep(const T* __restrict__ lut, const T* __restrict__ w, int nb, int64_t B,
-                                                  T* __restrict__ padded) {
-  int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  T acc = T(0);
-  T* dst = padded + b * NBP;
-  for (int j = 0; j < NBP - 1; ++j) {
-    T x = j < nb ? lut[b * nb + j] : T(0);
-    acc += (w && j < nb ? w[j] : T(1)) * x * x;
-    dst[j] = x;
-  }
-  dst[NBP - 1] = acc;
-}
-
-template <typename T, int NBP>
-__global__ __launch_bounds__(256) void k_lut_scan(const T* __restrict__ padded, const T* __restrict__ obs,
-                                                  const T* __restrict__ w, int nb, int64_t B, int64_t M, int nslice,
-                                                  T* __restrict__ part_cost, int64_t* __restrict__ part_idx) {
-  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int slice = blockIdx.y;
-  const int64_t mc = m < M ? m : M - 1;
-  T yw[NBP - 1];
-#pragma unroll
-  for (int j = 0; j < NBP - 1; ++j) yw[j] = (j < nb) ? T(-2) * (w ? w[j] : T(1)) * obs[mc * nb + j] : T(0);
-  const int64_t per = (B + nslice - 1) / nslice;
-  const int64_t b0 = per * slice;
-  const int64_t b1 = (b0 + per < B) ? b0 + per : B;
-  T best = INFINITY;
-  int64_t bi = -1;
-#pragma unroll 2
-  for (int64_t b = b0; b < b1; ++b) {
-    const T* __restrict__ x = padded + b * NBP;   // wave-uniform, NBP-aligned row -> one wide scalar load
-    T acc = x[NBP - 1];
-#pragma unroll
-    for (int j = 0; j < NBP - 1; ++j) acc += x[j] * yw[j];
-    if (acc < best) {
-      best = acc;
-      bi = b;
-    }
-  }
-  if (m < M) {
-    part_cost[(int64_t)slice * M + m] = best;
-    part_idx[(int64_t)slice * M + m] = bi;
-  }
-}
-
-
+// It is a GEMM with K = nb + 1 followed by an argmin and runs on the matrix cores in both dtypes (below); the LUT is cut
+// into `nslice` ranges of whole tiles so that the workgroups fill the chip; k_lut_reduce_tiles takes the minimum over
+// slices.  NaN rows never win.
 // float32 scan on the matrix cores (exact-f32 MFMA, v_mfma_f32_32x32x2_f32: bitwise an fmaf chain, so nothing changes
 // numerically against the vector form).  cost(b, m) = sum_k A[b][k] * Bq[k][m] is a GEMM with K = nb + 1:
 //   A[b][k]  = x_bk (k < nb), n_b = sum_j w_j x_bj^2 (k = nb), 0 beyond        -- the LUT rows
@@ -810,19 +760,20 @@ __global__ __launch_bounds__(256, 2) void k_lut_scan_mfma(const float* __restric
   }
 }
 
-// minimum over the (slice, half) partial results, then the row inside the winning 32-row tile by the directly
+// minimum over the (slice, lane-group) partial results, then the row inside the winning ROWS-row tile by the directly
 // evaluated cost sum_j w_j (x_j - y_j)^2 (which is also the cost that is reported): ascending + strict '<' = ties to
 // the lowest row index
-static __global__ __launch_bounds__(256) void k_lut_reduce_tiles(const float* __restrict__ part_cost, const int* __restrict__ part_tile,
-                                                          const float* __restrict__ lut, const float* __restrict__ obs,
-                                                          const float* __restrict__ w, int nb, int64_t B, int64_t M, int npart,
-                                                          int64_t* __restrict__ best_idx, float* __restrict__ best_cost) {
+template <typename T, int ROWS>
+__global__ __launch_bounds__(256) void k_lut_reduce_tiles(const T* __restrict__ part_cost, const int* __restrict__ part_tile,
+                                                          const T* __restrict__ lut, const T* __restrict__ obs,
+                                                          const T* __restrict__ w, int nb, int64_t B, int64_t M, int npart,
+                                                          int64_t* __restrict__ best_idx, T* __restrict__ best_cost) {
   const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= M) return;
-  float best = INFINITY;
+  T best = INFINITY;
   int bt = -1;
   for (int p = 0; p < npart; ++p) {
-    const float c = part_cost[(int64_t)p * M + m];
+    const T c = part_cost[(int64_t)p * M + m];
     const int t = part_tile[(int64_t)p * M + m];
     if (t >= 0 && (c < best || (c == best && t < bt))) {
       best = c;
@@ -830,14 +781,14 @@ static __global__ __launch_bounds__(256) void k_lut_reduce_tiles(const float* __
     }
   }
   int64_t bi = -1;
-  float bc = INFINITY;
+  T bc = INFINITY;
   if (bt >= 0) {
-    const int64_t r0 = (int64_t)bt * 32, r1 = (r0 + 32 < B) ? r0 + 32 : B;
+    const int64_t r0 = (int64_t)bt * ROWS, r1 = (r0 + ROWS < B) ? r0 + ROWS : B;
     for (int64_t r = r0; r < r1; ++r) {
-      float c = 0.0f;
+      T c = T(0);
       for (int j = 0; j < nb; ++j) {
-        const float d = lut[r * nb + j] - obs[m * nb + j];
-        c += (w ? w[j] : 1.0f) * d * d;
+        const T d = lut[r * nb + j] - obs[m * nb + j];
+        c += (w ? w[j] : T(1)) * d * d;
       }
       if (c < bc) {
         bc = c;
@@ -849,36 +800,99 @@ static __global__ __launch_bounds__(256) void k_lut_reduce_tiles(const float* __
   best_cost[m] = bc;
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void k_lut_reduce(const T* __restrict__ part_cost, const int64_t* __restrict__ part_idx,
-                                                    const T* __restrict__ lut, const T* __restrict__ obs,
-                                                    const T* __restrict__ w, int nb, int64_t M, int nslice,
-                                                    int64_t* __restrict__ best_idx, T* __restrict__ best_cost) {
-  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= M) return;
-  T best = INFINITY;
-  int64_t bi = -1;
-  for (int s = 0; s < nslice; ++s) {             // ascending slices + strict '<': ties go to the lowest row index
-    T c = part_cost[(int64_t)s * M + m];
-    if (c < best) {
-      best = c;
-      bi = part_idx[(int64_t)s * M + m];
+// float64: the same scan on v_mfma_f64_16x16x4_f64 (K steps of 4, 16 x 16 tiles, four accumulator values per lane: lane l
+// holds four LUT rows of observation l % 16; the four lane groups l / 16 keep separate partial minima).
+typedef double spart_d4v __attribute__((ext_vector_type(4)));
+
+template <int KS>
+__global__ __launch_bounds__(256) void k_lut_prep_mfma64(const double* __restrict__ lut, const double* __restrict__ w, int nb,
+                                                         int64_t B, int64_t ntile, double* __restrict__ tiles) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= ntile * KS * 64) return;
+  const int lane = (int)(e & 63), kk = (int)((e >> 6) % KS);
+  const int64_t t = (e >> 6) / KS;
+  const int64_t row = t * 16 + (lane & 15);
+  const int col = 4 * kk + (lane >> 4);
+  double v = 0.0;
+  if (row < B) {
+    if (col < nb) {
+      v = lut[row * nb + col];
+    } else if (col == nb) {
+      for (int j = 0; j < nb; ++j) {
+        const double x = lut[row * nb + j];
+        v += (w ? w[j] : 1.0) * x * x;
+      }
+    }
+  } else if (col == nb) {
+    v = INFINITY;
+  }
+  tiles[e] = v;
+}
+
+template <int KS, int TO>
+__global__ __launch_bounds__(256, 2) void k_lut_scan_mfma64(const double* __restrict__ tiles, const double* __restrict__ obs,
+                                                            const double* __restrict__ w, int nb, int64_t ntile, int64_t M,
+                                                            int nslice, double* __restrict__ part_cost, int* __restrict__ part_tile) {
+  const int lane = threadIdx.x & 63;
+  const int64_t m0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (16 * TO);
+  if (m0 >= M) return;
+  const int slice = blockIdx.y;
+  const int j = lane & 15, q = lane >> 4;
+  double bq[TO][KS];
+#pragma unroll
+  for (int blk = 0; blk < TO; ++blk) {
+    const int64_t m = m0 + blk * 16 + j;
+    const int64_t mc = m < M ? m : M - 1;
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      const int col = 4 * kk + q;
+      bq[blk][kk] = col < nb ? -2.0 * (w ? w[col] : 1.0) * obs[mc * nb + col] : (col == nb ? 1.0 : 0.0);
     }
   }
-  // The scan ranks rows by n_b - 2 sum w x y (+ sum w y^2): in float32 that difference of O(|y|^2) terms carries an
-  // absolute error of ~1e-7 |y|^2, fine for ranking reflectances but not a cost to report (radiance-scale columns,
-  // exact members).  The winner's cost is therefore recomputed directly, sum_j w_j (x_j - y_j)^2, from its LUT row.
-  T c = T(0);
-  if (bi >= 0) {
-    for (int j = 0; j < nb; ++j) {
-      const T d = lut[bi * nb + j] - obs[m * nb + j];
-      c += (w ? w[j] : T(1)) * d * d;
-    }
-  } else {
-    c = INFINITY;                                // no finite row at all
+  const int64_t per = (ntile + nslice - 1) / nslice;
+  const int64_t t0 = per * slice;
+  const int64_t t1 = (t0 + per < ntile) ? t0 + per : ntile;
+  double best[TO];
+  int bt[TO];
+#pragma unroll
+  for (int blk = 0; blk < TO; ++blk) {
+    best[blk] = INFINITY;
+    bt[blk] = -1;
   }
-  best_idx[m] = bi;
-  best_cost[m] = c;
+  if (t0 < t1) {
+    const double* __restrict__ ap = tiles + t0 * (KS * 64) + lane;
+    double a[KS];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) a[kk] = ap[kk * 64];
+    for (int64_t t = t0; t < t1; ++t) {
+      if (t + 1 < t1) ap += KS * 64;
+      double an[KS];
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) an[kk] = ap[kk * 64];
+#pragma unroll
+      for (int blk = 0; blk < TO; ++blk) {
+        spart_d4v acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], bq[blk][kk], acc, 0, 0, 0);
+        const double mn = __builtin_fmin(__builtin_fmin(acc[0], acc[1]), __builtin_fmin(acc[2], acc[3]));
+        if (mn < best[blk]) {
+          best[blk] = mn;
+          bt[blk] = (int)(t - t0);
+        }
+      }
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) a[kk] = an[kk];
+    }
+  }
+#pragma unroll
+  for (int blk = 0; blk < TO; ++blk) {
+    const int64_t m = m0 + blk * 16 + j;
+    if (m < M) {
+      const int64_t o = ((int64_t)slice * 4 + q) * M + m;
+      part_cost[o] = best[blk];
+      part_tile[o] = bt[blk] < 0 ? -1 : (int)(t0 + bt[blk]);
+    }
+  }
 }
 
 }  // namespace spart

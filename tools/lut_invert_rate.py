@@ -9,7 +9,7 @@ from spart_amd.engine import Engine
 eng = Engine(None, 0, lib_path=sys.argv[1] if len(sys.argv) > 1 else None)
 for dtype, td in (("float32", torch.float32), ("float64", torch.float64)):
     for B, M, nb in ((1_000_000, 4096, 13), (1_000_000, 65536, 13), (10_000_000, 4096, 13), (1_000_000, 65536, 21), (1_000_000, 65536, 6)):
-        if dtype == "float64" and (M > 4096 or B > 1_000_000):
+        if dtype == "float64" and B > 1_000_000:
             continue
         lut = torch.rand((B, nb), device="cuda:0", dtype=td); obs = torch.rand((M, nb), device="cuda:0", dtype=td)
         eng.lut_nearest(lut, obs, dtype=dtype); torch.cuda.synchronize()
