@@ -373,7 +373,12 @@ def mode_records(torch, args, dev):
                      "note": f"cost(b, m) = sum_k A[b][k] Bq[k][m], K = {nbp} (nb + 1 incl. the norm slot, in MFMA steps of 2): 2 x {nbp} flops "
                              "per comparison on v_mfma_f32_32x32x2_f32 (exact f32); peak = the f32-input MFMA peak 157.3 TF "
                              "(MI355X_MICROARCH.md: equal to the vector peak); whole call timed (prep + scan + reduce)"}}
-    del lut, obs, idx, cost, d, pick
+    l64, o64 = lut.double(), obs.double()
+    eng0.lut_nearest(l64, o64, dtype="float64")
+    sec64 = timed(torch, lambda: eng0.lut_nearest(l64, o64, dtype="float64"), 3, 1)
+    rec["lut_invert"]["fp64"] = {"value": lut.shape[0] * M / sec64, "unit": "row comparisons/s", "ms_per_step": sec64 * 1e3,
+                                 "note": "the same search in float64 on v_mfma_f64_16x16x4_f64 (K = 16)"}
+    del lut, obs, idx, cost, d, pick, l64, o64
     torch.cuda.empty_cache()
     # --- LUT generation end to end: host parameter table in, host columns out (PCIe-inclusive; never the headline)
     P8 = np.tile(P1m, (8, 1))
