@@ -38,9 +38,9 @@ struct ParamPtrs {
 
 // ------------------------------------------------------------------------------------------
 // Workspace layout of the per-sample quantities: STRUCTURE OF ARRAYS with row pitch Bp (= B rounded up to 64):
-//   cst[i][s]  (48 rows, float and / or double), atm[i][s] (16 rows, double), G[slot][4][s], gsoil[slot][s].
+//   cst[i][s]  (NCONST = 40 rows, float and / or double), atm[i][s] (16 rows, double), G[slot][4][s], gsoil[slot][s].
 // Every kernel that has the sample on its lanes (prelude, sensor-slot pass, sensor kernel) then reads and writes
-// them coalesced; the band kernels (band on lanes) stage 32 samples x 48 constants per workgroup copy.
+// them coalesced; the band kernels (band on lanes) stage 32 samples x 40 constants per workgroup copy.
 inline int64_t row_pitch_of(int64_t B) { return (B + 63) & ~int64_t(63); }
 
 // A sample's constants seen from a band kernel: either contiguous in LDS (plain pointer) or column s of the
@@ -51,8 +51,8 @@ template <typename T> struct ConstCol {
   __device__ __forceinline__ T operator[](int i) const { return p[(int64_t)i * stride]; }
 };
 
-// One workgroup copy of 32 samples x 48 constants from the structure-of-arrays block (blk = &cst[0][first sample]) into
-// LDS as [sample][48]: lanes 32 r .. 32 r + 31 read 128 contiguous bytes of row r + 8 k.  The row base is wave-uniform
+// One workgroup copy of 32 samples x NCONST (40) constants from the structure-of-arrays block (blk = &cst[0][first sample]) into
+// LDS as [sample][NCONST]: lanes 32 r .. 32 r + 31 read 128 contiguous bytes of row r + 8 k.  The row base is wave-uniform
 // (SGPRs) and the lane carries ONE loop-invariant 32-bit byte offset (host: 8 Bp sizeof(T) < 4 GB), so nothing but
 // that register stays live across the sample loop.
 template <typename T>
@@ -224,8 +224,8 @@ void k_bands(const T* __restrict__ tab, const T* __restrict__ cst, int64_t Bp, i
     if (mat.leaf_kchl) mat.leaf_kchl += b0o;
     if (mat.soil_dry) mat.soil_dry += b0o;
   }
-  // Per-sample constants are staged through LDS, 32 samples (6 KB fp32) at a time: one coalesced copy by the
-  // workgroup, then every wave reads sample s's 48 values with wave-uniform ds_read_b128 (a broadcast).  They
+  // Per-sample constants are staged through LDS, 32 samples (5 KB fp32) at a time: one coalesced copy by the
+  // workgroup, then every wave reads sample s's 40 values with wave-uniform ds_read_b128 (a broadcast).  They
   // land in VGPRs: on gfx950 a VALU op with an SGPR source issues ~1.6x slower than with VGPR / literal sources
   // (profiles/r1_ubench_valu_issue.txt), and ~60 ops per band use these constants -- the same kernel with
   // scalar loads (s_load_dwordx8 -> SGPR operands) is 6 % slower.
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256) void k_bandmean(const T* __restrict__ bandsum,
 }
 
 // ------------------------------------------------------------------------------------------
-// Walk samples s0..s1 with their 48 constants staged through LDS, 32 samples per coalesced workgroup copy (the
+// Walk samples s0..s1 with their 40 constants staged through LDS, 32 samples per coalesced workgroup copy (the
 // stage-level kernels below; k_bands has the same loop written out).  body(s, c): c points at sample s's constants
 // in LDS (wave-uniform address -> broadcast reads).  Without the staging every sample starts with a scalar load
 // from global memory whose latency nothing hides: k_bsm, 55 VALU instructions per band, was bound by exactly that.
@@ -645,7 +645,7 @@ static __global__ __launch_bounds__(64) void k_econv(const double* __restrict__ 
 // ------------------------------------------------------------------------------------------
 // LUT inversion (no counterpart in the reference): for every observed spectrum find the LUT
 // row with the smallest weighted squared distance  sum_j w_j (x_bj - y_mj)^2.
-//   cost(b, m) = n_b + sum_j x_bj * (-2 w_j y_mj) + sum_j w_j y_mj^2,   n_b = sum_j w_j x_bj^2 (k_lut_norms)
+//   cost(b, m) = n_b + sum_j x_bj * (-2 w_j y_mj) + sum_j w_j y_mj^2,   n_b = sum_j w_j x_bj^2 (computed by the prep kernels)
 // It is a GEMM with K = nb + 1 followed by an argmin and runs on the matrix cores in both dtypes (below); the LUT is cut
 // into `nslice` ranges of whole tiles so that the workgroups fill the chip; k_lut_reduce_tiles takes the minimum over
 // slices.  NaN rows never win.
