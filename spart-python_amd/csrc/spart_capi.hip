@@ -340,8 +340,7 @@ static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_
   const bool fork = bands && ctx->side != nullptr;
   hipStream_t s2 = fork ? ctx->side : st;
   auto columns = [&]() -> int {                // slot pass + sensor kernel, on s2
-    const int64_t nblk = (B + 255) / 256;                            // 256-sample blocks, dealt to the XCDs in groups of 8
-    hipLaunchKernelGGL((k_slots<TG, TO>), dim3((unsigned)(((nblk + 7) / 8) * 8 * ctx->nslot)), dim3(256), 0, s2, tabG,
+    hipLaunchKernelGGL((k_slots<TG, TO>), dim3((unsigned)((B + 63) / 64)), dim3(256), 0, s2, tabG,
                        cstG, Bp, (const int*)ctx->slot_band, G, (TG*)(want_rsoil ? gs : nullptr),
                        (const TO*)(opt ? opt->rdry_in : nullptr), ctx->po, B, ctx->nslot);
     HIP_TRY(ctx, hipGetLastError());

@@ -329,12 +329,9 @@ void k_bands(const T* __restrict__ tab, const T* __restrict__ cst, int64_t Bp, i
   }
 }
 
-// The sensor-slot pass: only the <= 2 nb bands the sensor columns depend on are evaluated.  Lane = sample, one
-// workgroup = 256 samples x ONE slot: the band's 17 table values are wave-uniform (scalar loads), the sample's
-// constants and the G rows are read / written coalesced (structure of arrays).  Block map (XCD-aware, cdna guide T1):
-// the nslot workgroups of one 256-sample block get ids x, x + 8, ..., i.e. the same XCD back to back, so that the
-// block's 40 constants x 256 samples are fetched from HBM once and re-read from that XCD's L2 (with the slot on
-// blockIdx.y the kernel moved nslot x 320 B per sample through HBM / MALL and was bound by that: 0.57 ms per 1M).  Identical arithmetic (leaf_band / soil_band /
+// The sensor-slot pass: only the <= 2 nb bands the sensor columns depend on are evaluated.  Lane = sample; the band's 17
+// table values are wave-uniform (scalar loads), the G rows are written coalesced (structure of arrays); the mapping of
+// samples and slots to workgroups is described at the kernel.  Identical arithmetic (leaf_band / soil_band /
 // canopy_band), ~150x less work than k_bands.  Two uses:
 //   * T = double in the default float32 mode: the G rows (and the debug rsoil values) that k_sensor turns into
 //     R_TOC / R_TOA / L_TOA are float64 whatever the dtype of the full-band kernel, so the float32 mode's columns are
@@ -342,38 +339,55 @@ void k_bands(const T* __restrict__ tab, const T* __restrict__ cst, int64_t Bp, i
 //     reference's canopy formulas cancel, sailh.py:185-214, and float32 band arithmetic then misses 1e-4);
 //   * spart_materialize.prune_unused_bands = 1 (NOT "full spectra"): the full-band kernel is skipped altogether.
 // TR: element type of the optional user dry-soil spectra (they arrive in the call's dtype).
+// a sample's constants in LDS as [NCONST][64] (lane = sample): p points at this lane's column
+template <typename T> struct LdsCol {
+  const T* p;
+  __device__ __forceinline__ T operator[](int i) const { return p[i * 64]; }
+};
+
+// One workgroup = 64 samples (lane = sample) x 4 waves; the block's 40 x 64 constants are copied into LDS once and wave w
+// walks the slots w, w + 4, ...: every slot's band arithmetic then reads its 36 constants from LDS (conflict-free: lane l
+// reads word l of a row) instead of pulling them through L2 again -- with one workgroup per (256 samples, slot) the
+// kernel moved nslot x 288 B per sample from L2 and was bound by that (0.35 ms per 1M; 0.13 ms of float64 arithmetic).
 template <typename T, typename TR>
 __global__ __launch_bounds__(256) void k_slots(const T* __restrict__ tab, const T* __restrict__ cst, int64_t Bp,
                                                const int* __restrict__ slot_band, T* __restrict__ G,
                                                T* __restrict__ gsoil, const TR* __restrict__ rdry_in, int po, int64_t B,
                                                int nslot) {
-  if (sizeof(T) == 8) stage_f64_tables();                      // (before any thread leaves: it ends with a barrier)
-  const unsigned per = 8u * (unsigned)nslot, within = blockIdx.x % per;
-  const int q = (int)(within >> 3);
-  const int64_t s = ((int64_t)(blockIdx.x / per) * 8 + (within & 7u)) * blockDim.x + threadIdx.x;
-  if (s >= B) return;
-  const int band = slot_band[q];
-  const bool thermal = band == NWL;
-  const int ti = band < NWL ? band : NWL - 1;
-  const BandTab<T> tb = load_tab(tab, ti);
-  const ConstCol<T> c{cst + s, Bp};
-  T refl, tran, absb, K;
-  leaf_band<T>(tb, c[C_CAB], c[C_CCA], c[C_CDM], c[C_CW], c[C_CS], c[C_CANT], c[C_CBC], c[C_PROT], c[C_NM1], refl,
-               tran, absb, K);
-  T rho = thermal ? c[C_RHO_TH] : refl;
-  T tau = thermal ? c[C_TAU_TH] : tran;
-  T ab = thermal ? (T(1) - c[C_RHO_TH] - c[C_TAU_TH]) : absb;
-  const CanopyPar<T> cp = load_canopy<T>(c);                   // (same order of the parts as in k_bands)
-  const CanopyCore<T> core = canopy_core<T>(cp, rho, tau, ab);
-  T rdry = rdry_in ? (T)rdry_in[s * po + ti] : soil_dry<T>(tb, c[C_F1], c[C_F2], c[C_F3]);
-  T fm[7] = {c[C_FM0], c[C_FM1], c[C_FM2], c[C_FM3], c[C_FM4], c[C_FM5], c[C_FM6]};
-  T rwet;
-  soil_band<T>(tb, rdry, c[C_WET], fm, c[C_FMSUM], c[C_FILM2L], rwet);
-  T rso, rdo, rsd, rdd;
-  canopy_soil<T>(cp, core, rwet, rso, rdo, rsd, rdd);
-  T* g = G + (int64_t)q * 4 * Bp + s;
-  g[0] = rso; g[Bp] = rdo; g[2 * Bp] = rsd; g[3 * Bp] = rdd;
-  if (gsoil) gsoil[(int64_t)q * Bp + s] = rwet;
+  __shared__ T lds_c[NCONST * 64];
+  if (sizeof(T) == 8) stage_f64_tables();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int64_t s = (int64_t)blockIdx.x * 64 + lane;
+  const int64_t sc = s < B ? s : B - 1;
+  constexpr int nwave = 4;                   // (more waves per workgroup measured slower: 7 / 13 / 16 -> +17 / +35 / +34 %)
+  for (int i = wave; i < NCONST; i += nwave) lds_c[i * 64 + lane] = cst[(int64_t)i * Bp + sc];
+  __syncthreads();
+  if (s >= B) return;                                            // (no barrier below)
+  const LdsCol<T> c{lds_c + lane};
+  for (int q = wave; q < nslot; q += nwave) {
+    const int band = slot_band[q];
+    const bool thermal = band == NWL;
+    const int ti = band < NWL ? band : NWL - 1;
+    const BandTab<T> tb = load_tab(tab, ti);
+    T refl, tran, absb, K;
+    leaf_band<T>(tb, c[C_CAB], c[C_CCA], c[C_CDM], c[C_CW], c[C_CS], c[C_CANT], c[C_CBC], c[C_PROT], c[C_NM1], refl,
+                 tran, absb, K);
+    T rho = thermal ? c[C_RHO_TH] : refl;
+    T tau = thermal ? c[C_TAU_TH] : tran;
+    T ab = thermal ? (T(1) - c[C_RHO_TH] - c[C_TAU_TH]) : absb;
+    const CanopyPar<T> cp = load_canopy<T>(c);                   // (same order of the parts as in k_bands)
+    const CanopyCore<T> core = canopy_core<T>(cp, rho, tau, ab);
+    T rdry = rdry_in ? (T)rdry_in[s * po + ti] : soil_dry<T>(tb, c[C_F1], c[C_F2], c[C_F3]);
+    T fm[7] = {c[C_FM0], c[C_FM1], c[C_FM2], c[C_FM3], c[C_FM4], c[C_FM5], c[C_FM6]};
+    T rwet;
+    soil_band<T>(tb, rdry, c[C_WET], fm, c[C_FMSUM], c[C_FILM2L], rwet);
+    T rso, rdo, rsd, rdd;
+    canopy_soil<T>(cp, core, rwet, rso, rdo, rsd, rdd);
+    T* g = G + (int64_t)q * 4 * Bp + s;
+    g[0] = rso; g[Bp] = rdo; g[2 * Bp] = rsd; g[3 * Bp] = rdd;
+    if (gsoil) gsoil[(int64_t)q * Bp + s] = rwet;
+  }
 }
 
 // batch-mean canopy spectra from the per-chunk band sums: out (4, 2162) = mean over samples of rso, rdo, rsd, rdd
