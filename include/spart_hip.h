@@ -175,20 +175,30 @@ int spart_run_batch(spart_ctx *ctx, int dtype, int64_t B, const double *const pa
                     const double *rho_thermal, const double *tau_thermal, void *R_TOC, void *R_TOA, void *L_TOA,
                     const spart_materialize *opt, void *workspace, size_t workspace_bytes, void *stream);
 
-/* LUT inversion (the use LUTs are generated for -- no counterpart in the reference):
- * for each of M observed sensor spectra obs (M,nb) find the row of lut (B,nb) that minimises
- * sum_j w_j (lut[b,j] - obs[m,j])^2 (weights (nb,) optional, NULL = 1).  best_idx (M,) int64, best_cost (M,) =
- * that minimum (divide by nb and take the root for an RMSE), evaluated directly from the winning row; ties go to
- * the lowest row index; NaN rows never win (-1 / +inf when no row has a finite cost).
- * The search is a GEMM with K = nb + 1 on the matrix cores -- exact-f32 v_mfma_f32_32x32x2_f32 (bitwise an fmaf chain) for
- * SPART_F32, v_mfma_f64_16x16x4_f64 for SPART_F64 -- which RANKS the tiles of 32 / 16 LUT rows by |x|^2 - 2 x.y; inside the
- * winning tile the row is picked by the directly evaluated cost.  In float32, tiles whose best distances to an observation
- * differ by less than ~1e-7 |y|^2 may therefore swap (use SPART_F64 for radiance-scale columns or single-band LUTs).
- * All pointers are device memory in `dtype`; nb <= 31. */
+/* LUT inversion (the use LUTs are generated for.  The only nearest-index search in the reference is
+ * an exact np.argmin with first-index ties, SPART.py:381-387 -- the behaviour kept here):
+ * for each of M observed sensor spectra obs (M,nb) find THE row of lut (B,nb) that minimises
+ *     c(b, m) = sum_j w_j (lut[b,j] - obs[m,j])^2      (weights (nb,) optional, NULL = 1; expected >= 0)
+ * where c is evaluated in `dtype` as  c = 0; for j ascending: d = lut[b,j] - obs[m,j]; c = c + (w_j * d) * d  with every
+ * operation rounded to `dtype` and no fused multiply-add.  best_idx (M,) int64 = the LOWEST row index attaining the minimum
+ * of that c (bit-exact: the same answer as a brute-force loop, in both dtypes, for any nb), best_cost (M,) = that minimum
+ * (divide by nb and take the root for an RMSE).  Rows or observations whose cost is NaN / +inf never win (-1 / +inf when no
+ * row has a finite cost).
+ * How: a GEMM with K = nb + 1 on the matrix cores -- exact-f32 v_mfma_f32_32x32x2_f32 for SPART_F32,
+ * v_mfma_f64_16x16x4_f64 for SPART_F64 -- over the CENTRED LUT (per-band mean removed) ranks the tiles of 32 / 16 LUT rows by
+ * |x'|^2 - 2 x'.y'; every tile whose minimum lies within a proven rounding bound of the best one is then evaluated row by
+ * row with c itself, and an observation for which the scan may have missed such a tile is re-done by a brute-force kernel
+ * (csrc/spart_lut.h derives the bound).  The data only decide how much of that extra work there is, never the result.
+ * All pointers are device memory in `dtype`; nb <= 31; B, M <= 2e9. */
 size_t spart_lut_workspace_bytes(int dtype, int64_t B, int nb, int64_t M);
 int spart_lut_nearest(spart_ctx *ctx, int dtype, int64_t B, int nb, const void *lut, int64_t M, const void *obs,
                       const void *weights, int64_t *best_idx, void *best_cost, void *workspace, size_t workspace_bytes,
                       void *stream);
+/* Diagnostics of the LAST spart_lut_nearest call that used `workspace` (same dtype, B, nb, M): the number of observations
+ * that took the brute-force path and Nmax = max_b sum_j |w_j| (lut[b,j] - centre_j)^2, the scale of the rounding bound.
+ * Synchronises the device (a blocking copy of 16 bytes).  No reference counterpart. */
+int spart_lut_stats(spart_ctx *ctx, int dtype, int64_t B, int nb, int64_t M, const void *workspace, int64_t *n_brute_force,
+                    double *nmax);
 
 /* Measurement aid (bench.py): when enabled, spart_run_batch brackets each of its kernels with HIP events recorded on
  * the caller's stream, for up to max_calls calls (max_calls = 0 disables).  spart_profile_read_stages waits for them

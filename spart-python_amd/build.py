@@ -19,7 +19,7 @@ CSRC = os.path.join(HERE, "csrc")
 SRC = os.path.join(CSRC, "spart_capi.hip")
 SOURCES = [SRC, os.path.join(CSRC, "spart_bands_f32.hip")]
 DEPS = SOURCES + [os.path.join(CSRC, f) for f in ("spart_kernels.h", "spart_math.h", "spart_e3_coeffs.h", "spart_f64_tables.h",
-                                                  "spart_bands_f32.h")] + [os.path.join(HERE, "..", "include", "spart_hip.h")]
+                                                  "spart_bands_f32.h", "spart_lut.h")] + [os.path.join(HERE, "..", "include", "spart_hip.h")]
 OUT = os.path.join(HERE, "libspart_hip.so")
 # -fno-slp-vectorize: hipcc's SLP pass packs independent fp32 ops into v_pk_mul/v_pk_fma, which issue at
 # half rate on gfx950 and block FMA contraction; the VALU-bound band kernel is 12 % faster without it

@@ -15,6 +15,7 @@
 #include "../../include/spart_hip.h"
 #include "spart_bands_f32.h"
 #include "spart_kernels.h"
+#include "spart_lut.h"
 
 using namespace spart;
 
@@ -407,7 +408,15 @@ static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_
   return SPART_OK;
 }
 
-// float64: the same GEMM + argmin on v_mfma_f64_16x16x4_f64 (k_lut_scan_mfma64): K steps of 4, 16-row tiles
+// ---- LUT inversion (csrc/spart_lut.h): GEMM + argmin on the matrix cores as a filter, exact direct evaluation of every
+// candidate, brute-force fallback.  float32: K steps of 2 (v_mfma_f32_32x32x2_f32), KS = ceil((nb + 1) / 2) MFMAs per
+// 32 x 32 comparisons, rounded up to one of the compiled variants; float64: K steps of 4 (v_mfma_f64_16x16x4_f64).
+static int lut_ks(int nb) {
+  const int need = (nb + 2) / 2;
+  for (int ks : {4, 7, 8, 11, 16})
+    if (ks >= need) return ks;
+  return 16;
+}
 static int lut_ks64(int nb) {
   const int need = (nb + 4) / 4;                      // ceil((nb + 1) / 4)
   for (int ks : {2, 4, 6, 8})
@@ -415,84 +424,111 @@ static int lut_ks64(int nb) {
   return 8;
 }
 static int lut_to64(int ks) { return ks <= 4 ? 8 : 4; }     // 16-observation blocks per wave (operand registers: 2 KS TO)
-static int lut_slices_mfma64(int64_t M, int64_t ntile, int to) {
-  const int64_t mg = (M + 16 * to * 4 - 1) / (16 * to * 4);
+// workgroups = ceil(M / obs per workgroup) x nslice; slices are whole tiles
+static int lut_slices(int64_t M, int64_t ntile, int obs_per_wg) {
+  const int64_t mg = (M + obs_per_wg - 1) / obs_per_wg;
   int64_t n = (4096 + mg - 1) / mg;
   if (n > ntile) n = ntile;
   if (n > 1024) n = 1024;
   if (n < 1) n = 1;
   return (int)n;
-}
-static int lut_impl_f64(spart_ctx* ctx, int64_t B, int nb, const void* lut, int64_t M, const void* obs, const void* weights,
-                        int64_t* best_idx, void* best_cost, char* wsp, hipStream_t st) {
-  const int ks = lut_ks64(nb), to = lut_to64(ks);
-  const int64_t ntile = (B + 15) / 16;
-  const int nslice = lut_slices_mfma64(M, ntile, to);
-  double* tiles = (double*)wsp;
-  double* pc = (double*)(wsp + align_up((size_t)ntile * ks * 64 * 8));
-  int* pt = (int*)((char*)pc + align_up((size_t)nslice * 4 * M * 8));
-  const dim3 gprep((unsigned)((ntile * ks * 64 + 255) / 256));
-  const dim3 grid((unsigned)((M + 16 * to * 4 - 1) / (16 * to * 4)), (unsigned)nslice);
-#define SPART_LUT_KS(K, TO)                                                                                                 \
-  case K:                                                                                                                    \
-    hipLaunchKernelGGL((k_lut_prep_mfma64<K>), gprep, dim3(256), 0, st, (const double*)lut, (const double*)weights, nb, B,   \
-                       ntile, tiles);                                                                                        \
-    hipLaunchKernelGGL((k_lut_scan_mfma64<K, TO>), grid, dim3(256), 0, st, (const double*)tiles, (const double*)obs,         \
-                       (const double*)weights, nb, ntile, M, nslice, pc, pt);                                                \
-    break;
-  switch (ks) {
-    SPART_LUT_KS(2, 8) SPART_LUT_KS(4, 8) SPART_LUT_KS(6, 4) SPART_LUT_KS(8, 4)
-  }
-#undef SPART_LUT_KS
-  HIP_TRY(ctx, hipGetLastError());
-  hipLaunchKernelGGL((k_lut_reduce_tiles<double, 16>), dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, (const double*)pc,
-                     (const int*)pt, (const double*)lut, (const double*)obs, (const double*)weights, nb, B, M, 4 * nslice,
-                     best_idx, (double*)best_cost);
-  HIP_TRY(ctx, hipGetLastError());
-  return SPART_OK;
 }
 
-// float32: the scan is a GEMM with K = nb + 1 on the exact-f32 matrix cores (k_lut_scan_mfma).  K steps of 2:
-// KS = ceil((nb + 1) / 2) MFMAs per 32 x 32 comparisons, rounded up to one of the compiled variants.
-static int lut_ks(int nb) {
-  const int need = (nb + 2) / 2;
-  for (int ks : {4, 7, 8, 11, 16})
-    if (ks >= need) return ks;
-  return 16;
-}
-// workgroups = ceil(M / 512) x nslice; slices are whole 32-row tiles
-static int lut_slices_mfma(int64_t M, int64_t ntile) {
-  const int64_t mg = (M + 32 * LUT_TO * 4 - 1) / (32 * LUT_TO * 4);
-  int64_t n = (4096 + mg - 1) / mg;
-  if (n > ntile) n = ntile;
-  if (n > 1024) n = 1024;
-  if (n < 1) n = 1;
-  return (int)n;
-}
-static int lut_impl_f32(spart_ctx* ctx, int64_t B, int nb, const void* lut, int64_t M, const void* obs, const void* weights,
-                        int64_t* best_idx, void* best_cost, char* wsp, hipStream_t st) {
-  const int ks = lut_ks(nb);
-  const int64_t ntile = (B + 31) / 32;
-  const int nslice = lut_slices_mfma(M, ntile);
-  float* tiles = (float*)wsp;
-  float* pc = (float*)(wsp + align_up((size_t)ntile * ks * 64 * 4));
-  int* pt = (int*)((char*)pc + align_up((size_t)nslice * 2 * M * 4));
-  const dim3 gprep((unsigned)((ntile * ks * 64 + 255) / 256));
-  const dim3 grid((unsigned)((M + 32 * LUT_TO * 4 - 1) / (32 * LUT_TO * 4)), (unsigned)nslice);
-#define SPART_LUT_KS(K)                                                                                                    \
-  case K:                                                                                                                  \
-    hipLaunchKernelGGL((k_lut_prep_mfma<K>), gprep, dim3(256), 0, st, (const float*)lut, (const float*)weights, nb, B, ntile, \
-                       tiles);                                                                                             \
-    hipLaunchKernelGGL((k_lut_scan_mfma<K>), grid, dim3(256), 0, st, (const float*)tiles, (const float*)obs,               \
-                       (const float*)weights, nb, ntile, M, nslice, pc, pt);                                               \
-    break;
-  switch (ks) {
-    SPART_LUT_KS(4) SPART_LUT_KS(7) SPART_LUT_KS(8) SPART_LUT_KS(11) SPART_LUT_KS(16)
+struct LutLayout {
+  int ks, to, rows, nslice, npart, kfma;
+  int64_t ntile, nfb;
+  size_t tiles, pc, ps, pt, centre, ctl, flags, fbc, fbi, total;
+};
+static LutLayout lut_layout(int dtype, int64_t B, int nb, int64_t M) {
+  LutLayout L;
+  const size_t es = dtype == SPART_F64 ? 8 : 4;
+  if (dtype == SPART_F32) {
+    L.rows = 32; L.ks = lut_ks(nb); L.to = LUT_TO; L.kfma = 2 * L.ks;
+  } else {
+    L.rows = 16; L.ks = lut_ks64(nb); L.to = lut_to64(L.ks); L.kfma = 4 * L.ks;
   }
-#undef SPART_LUT_KS
+  L.ntile = (B + L.rows - 1) / L.rows;
+  L.nslice = lut_slices(M, L.ntile, L.rows * L.to * 4);
+  L.npart = (64 / L.rows) * L.nslice;
+  const int64_t mgroups = (M + 63) / 64;
+  L.nfb = mgroups > (int64_t)LUT_FB_BLOCKS * 4 ? mgroups : (int64_t)LUT_FB_BLOCKS * 4;
+  size_t o = 0;
+  L.tiles = o;  o = align_up(o + (size_t)L.ntile * L.ks * 64 * es);
+  L.pc = o;     o = align_up(o + (size_t)L.npart * M * es);
+  L.ps = o;     o = align_up(o + (size_t)L.npart * M * es);
+  L.pt = o;     o = align_up(o + (size_t)L.npart * M * 4);
+  L.centre = o; o = align_up(o + 32 * es);
+  L.ctl = o;    o = align_up(o + LUT_CTL_WORDS * 8);
+  L.flags = o;  o = align_up(o + (size_t)M * 4);
+  L.fbc = o;    o = align_up(o + (size_t)L.nfb * 64 * es);
+  L.fbi = o;    o = align_up(o + (size_t)L.nfb * 64 * 8);
+  L.total = o;
+  return L;
+}
+// Delta = coef * (Nmax + Y): spart_lut.h derives 2 (3 nb + 2 K + 13) u; + 3 and 1 % for the second-order terms
+static double lut_delta_coef(int nb, int kfma, double u) { return 2.0 * (3.0 * nb + 2.0 * kfma + 16.0) * 1.01 * u; }
+
+template <typename T>
+static int lut_impl(spart_ctx* ctx, int dtype, int64_t B, int nb, const void* lut_, int64_t M, const void* obs_,
+                    const void* weights, int64_t* best_idx, void* best_cost, char* wsp, hipStream_t st) {
+  const LutLayout L = lut_layout(dtype, B, nb, M);
+  const T *lut = (const T*)lut_, *obs = (const T*)obs_, *w = (const T*)weights;
+  T* tiles = (T*)(wsp + L.tiles);
+  T* pc = (T*)(wsp + L.pc);
+  T* ps = (T*)(wsp + L.ps);
+  int* pt = (int*)(wsp + L.pt);
+  T* centre = (T*)(wsp + L.centre);
+  unsigned long long* ctl = (unsigned long long*)(wsp + L.ctl);
+  int* flags = (int*)(wsp + L.flags);
+  T* fbc = (T*)(wsp + L.fbc);
+  int64_t* fbi = (int64_t*)(wsp + L.fbi);
+  hipLaunchKernelGGL((k_lut_centre<T>), dim3(nb), dim3(256), 0, st, lut, nb, B, centre, ctl);
   HIP_TRY(ctx, hipGetLastError());
-  hipLaunchKernelGGL((k_lut_reduce_tiles<float, 32>), dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, (const float*)pc, (const int*)pt,
-                     (const float*)lut, (const float*)obs, (const float*)weights, nb, B, M, 2 * nslice, best_idx, (float*)best_cost);
+  const dim3 gprep((unsigned)((L.ntile * L.rows + 255) / 256));
+  const dim3 grid((unsigned)((M + L.rows * L.to * 4 - 1) / (L.rows * L.to * 4)), (unsigned)L.nslice);
+  if constexpr (sizeof(T) == 4) {
+#define SPART_LUT_KS(K)                                                                                                   \
+  case K:                                                                                                                  \
+    hipLaunchKernelGGL((k_lut_prep<float, K, 32>), gprep, dim3(256), 0, st, lut, w, (const float*)centre, nb, B, L.ntile,  \
+                       tiles, ctl);                                                                                        \
+    hipLaunchKernelGGL((k_lut_scan_mfma<K>), grid, dim3(256), 0, st, (const float*)tiles, obs, w, (const float*)centre,    \
+                       nb, L.ntile, M, L.nslice, pc, ps, pt);                                                              \
+    break;
+    switch (L.ks) { SPART_LUT_KS(4) SPART_LUT_KS(7) SPART_LUT_KS(8) SPART_LUT_KS(11) SPART_LUT_KS(16) }
+#undef SPART_LUT_KS
+  } else {
+#define SPART_LUT_KS(K, TO)                                                                                               \
+  case K:                                                                                                                  \
+    hipLaunchKernelGGL((k_lut_prep<double, K, 16>), gprep, dim3(256), 0, st, lut, w, (const double*)centre, nb, B,         \
+                       L.ntile, tiles, ctl);                                                                               \
+    hipLaunchKernelGGL((k_lut_scan_mfma64<K, TO>), grid, dim3(256), 0, st, (const double*)tiles, obs, w,                   \
+                       (const double*)centre, nb, L.ntile, M, L.nslice, pc, ps, pt);                                       \
+    break;
+    switch (L.ks) { SPART_LUT_KS(2, 8) SPART_LUT_KS(4, 8) SPART_LUT_KS(6, 4) SPART_LUT_KS(8, 4) }
+#undef SPART_LUT_KS
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  const T coef = (T)lut_delta_coef(nb, L.kfma, (double)LutNum<T>::u);
+  const dim3 gobs((unsigned)((M + 3) / 4));                // one wave per observation
+  hipLaunchKernelGGL((k_lut_reduce_exact<T, (sizeof(T) == 4 ? 32 : 16)>), gobs, dim3(256), 0, st, (const T*)pc, (const T*)ps,
+                     (const int*)pt, lut, obs, w, (const T*)centre, nb, B, M, L.npart, coef, ctl, flags, best_idx, (T*)best_cost);
+  HIP_TRY(ctx, hipGetLastError());
+  // the flagged observations (normally a handful, possibly all of them for degenerate data): the grid is fixed, the
+  // kernels read the count on the device, so the call stays asynchronous and graph-capturable
+  const int nbc = (nb + 3) / 4 * 4;
+  const size_t fb_lds = (size_t)4 * LUT_FB_ROWS * nbc * sizeof(T);
+#define SPART_LUT_FB(N)                                                                                                   \
+  case N:                                                                                                                  \
+    hipLaunchKernelGGL((k_lut_fallback<T, N>), dim3(LUT_FB_BLOCKS), dim3(256), fb_lds, st, lut, obs, w, nb, B,             \
+                       (const unsigned long long*)ctl, (const int*)flags, fbc, fbi);                                       \
+    break;
+  switch (nbc) {
+    SPART_LUT_FB(4) SPART_LUT_FB(8) SPART_LUT_FB(12) SPART_LUT_FB(16) SPART_LUT_FB(20) SPART_LUT_FB(24) SPART_LUT_FB(28) SPART_LUT_FB(32)
+  }
+#undef SPART_LUT_FB
+  HIP_TRY(ctx, hipGetLastError());
+  hipLaunchKernelGGL((k_lut_fallback_merge<T>), dim3(256), dim3(256), 0, st, B, LUT_FB_BLOCKS * 4, (const unsigned long long*)ctl,
+                     (const int*)flags, (const T*)fbc, (const int64_t*)fbi, best_idx, (T*)best_cost);
   HIP_TRY(ctx, hipGetLastError());
   return SPART_OK;
 }
@@ -833,16 +869,8 @@ int spart_run_batch(spart_ctx* ctx, int dtype, int64_t B, const double* const pa
 }
 
 size_t spart_lut_workspace_bytes(int dtype, int64_t B, int nb, int64_t M) {
-  if (B <= 0 || M <= 0 || nb < 1) return 0;
-  if (dtype == SPART_F32) {
-    const int64_t ntile = (B + 31) / 32;
-    const int nslice = lut_slices_mfma(M, ntile);
-    return align_up((size_t)ntile * lut_ks(nb) * 64 * 4) + 2 * align_up((size_t)nslice * 2 * M * 4);
-  }
-  const int64_t ntile = (B + 15) / 16;
-  const int ks = lut_ks64(nb);
-  const int nslice = lut_slices_mfma64(M, ntile, lut_to64(ks));
-  return align_up((size_t)ntile * ks * 64 * 8) + align_up((size_t)nslice * 4 * M * 8) + align_up((size_t)nslice * 4 * M * 4);
+  if (B <= 0 || M <= 0 || nb < 1 || nb > 31 || (dtype != SPART_F32 && dtype != SPART_F64)) return 0;
+  return lut_layout(dtype, B, nb, M).total;
 }
 
 int spart_lut_nearest(spart_ctx* ctx, int dtype, int64_t B, int nb, const void* lut, int64_t M, const void* obs,
@@ -850,7 +878,8 @@ int spart_lut_nearest(spart_ctx* ctx, int dtype, int64_t B, int nb, const void* 
                       void* stream) {
   if (!ctx) return fail(nullptr, SPART_ERR_INVALID, "spart_lut_nearest: null context");
   if (dtype != SPART_F32 && dtype != SPART_F64) return fail(ctx, SPART_ERR_INVALID, "spart_lut_nearest: bad dtype %d", dtype);
-  if (B < 0 || M < 0 || nb < 1 || nb > 31) return fail(ctx, SPART_ERR_INVALID, "spart_lut_nearest: bad sizes (B=%lld M=%lld nb=%d, nb <= 31)", (long long)B, (long long)M, nb);
+  if (B < 0 || M < 0 || nb < 1 || nb > 31 || B > 2000000000LL || M > 2000000000LL)
+    return fail(ctx, SPART_ERR_INVALID, "spart_lut_nearest: bad sizes (B=%lld M=%lld nb=%d; nb <= 31, B and M <= 2e9)", (long long)B, (long long)M, nb);
   if (M == 0) return SPART_OK;
   if (B == 0) return fail(ctx, SPART_ERR_INVALID, "spart_lut_nearest: empty LUT");
   if (!lut || !obs || !best_idx || !best_cost) return fail(ctx, SPART_ERR_INVALID, "spart_lut_nearest: null argument");
@@ -859,8 +888,28 @@ int spart_lut_nearest(spart_ctx* ctx, int dtype, int64_t B, int nb, const void* 
     return fail(ctx, SPART_ERR_WORKSPACE, "spart_lut_nearest: workspace of %zu bytes needed, %zu given", need, workspace_bytes);
   DeviceGuard guard(ctx->device);
   hipStream_t st = (hipStream_t)stream;
-  return dtype == SPART_F32 ? lut_impl_f32(ctx, B, nb, lut, M, obs, weights, best_idx, best_cost, (char*)workspace, st)
-                            : lut_impl_f64(ctx, B, nb, lut, M, obs, weights, best_idx, best_cost, (char*)workspace, st);
+  return dtype == SPART_F32 ? lut_impl<float>(ctx, dtype, B, nb, lut, M, obs, weights, best_idx, best_cost, (char*)workspace, st)
+                            : lut_impl<double>(ctx, dtype, B, nb, lut, M, obs, weights, best_idx, best_cost, (char*)workspace, st);
+}
+
+int spart_lut_stats(spart_ctx* ctx, int dtype, int64_t B, int nb, int64_t M, const void* workspace, int64_t* n_brute_force,
+                    double* nmax) {
+  if (!ctx) return fail(nullptr, SPART_ERR_INVALID, "spart_lut_stats: null context");
+  if (!workspace || !n_brute_force || !nmax || spart_lut_workspace_bytes(dtype, B, nb, M) == 0)
+    return fail(ctx, SPART_ERR_INVALID, "spart_lut_stats: bad argument");
+  DeviceGuard guard(ctx->device);
+  unsigned long long ctl[LUT_CTL_WORDS];
+  HIP_TRY(ctx, hipMemcpy(ctl, (const char*)workspace + lut_layout(dtype, B, nb, M).ctl, sizeof(ctl), hipMemcpyDeviceToHost));
+  *n_brute_force = (int64_t)ctl[1];
+  if (dtype == SPART_F32) {
+    const unsigned b = (unsigned)ctl[0];
+    float f;
+    std::memcpy(&f, &b, 4);
+    *nmax = f;
+  } else {
+    std::memcpy(nmax, &ctl[0], 8);
+  }
+  return SPART_OK;
 }
 
 }  // extern "C"

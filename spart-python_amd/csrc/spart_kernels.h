@@ -656,257 +656,4 @@ static __global__ __launch_bounds__(64) void k_econv(const double* __restrict__ 
   if (lane == 0) econv[b] = num / den;
 }
 
-// ------------------------------------------------------------------------------------------
-// LUT inversion (no counterpart in the reference): for every observed spectrum find the LUT
-// row with the smallest weighted squared distance  sum_j w_j (x_bj - y_mj)^2.
-//   cost(b, m) = n_b + sum_j x_bj * (-2 w_j y_mj) + sum_j w_j y_mj^2,   n_b = sum_j w_j x_bj^2 (computed by the prep kernels)
-// It is a GEMM with K = nb + 1 followed by an argmin and runs on the matrix cores in both dtypes (below); the LUT is cut
-// into `nslice` ranges of whole tiles so that the workgroups fill the chip; k_lut_reduce_tiles takes the minimum over
-// slices.  NaN rows never win.
-// float32 scan on the matrix cores (exact-f32 MFMA, v_mfma_f32_32x32x2_f32: bitwise an fmaf chain, so nothing changes
-// numerically against the vector form).  cost(b, m) = sum_k A[b][k] * Bq[k][m] is a GEMM with K = nb + 1:
-//   A[b][k]  = x_bk (k < nb), n_b = sum_j w_j x_bj^2 (k = nb), 0 beyond        -- the LUT rows
-//   Bq[k][m] = -2 w_k y_mk (k < nb), 1 (k = nb), 0 beyond                      -- the observations
-// A 32 x 32 x 2 MFMA takes ONE register of A (lane l: row l % 32, k = l / 32) and one of Bq (lane l: column l % 32,
-// k = l / 32); K = 2 KS is covered by KS of them chained on one 16-register accumulator (lane l ends up with 16 LUT
-// rows of observation l % 32).  Each wave keeps TO blocks of 32 observations in registers (TO x KS operand registers) and
-// streams the LUT tiles of its slice past them; k_lut_prep_mfma has laid the LUT out tile-major, [tile][kk][lane], so a
-// tile's operand registers are KS coalesced 256-byte loads.
-// The matrix pipe does the arithmetic (KS x 64 cycles per 1024 comparisons); the vector ALU only takes the minimum of
-// the 16 accumulator values (v_min3) and remembers WHICH TILE it came from (one compare + select per tile and block,
-// instead of a compare + two selects per comparison); k_lut_reduce_tiles finds the row inside the winning tile with
-// the directly evaluated cost.  NaN costs never win (v_min returns the other operand; comparisons with NaN are false);
-// rows past B are padded with n_b = +inf.
-typedef float spart_f16v __attribute__((ext_vector_type(16)));
-constexpr int LUT_TO = 4;                  // 32-observation blocks per wave (128 observations, 4 KS operand registers)
-
-template <int KS>
-__global__ __launch_bounds__(256) void k_lut_prep_mfma(const float* __restrict__ lut, const float* __restrict__ w, int nb,
-                                                       int64_t B, int64_t ntile, float* __restrict__ tiles) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= ntile * KS * 64) return;
-  const int lane = (int)(e & 63), kk = (int)((e >> 6) % KS);
-  const int64_t t = (e >> 6) / KS;
-  const int64_t row = t * 32 + (lane & 31);
-  const int col = 2 * kk + (lane >> 5);
-  float v = 0.0f;
-  if (row < B) {
-    if (col < nb) {
-      v = lut[row * nb + col];
-    } else if (col == nb) {
-      for (int j = 0; j < nb; ++j) {
-        const float x = lut[row * nb + j];
-        v += (w ? w[j] : 1.0f) * x * x;
-      }
-    }
-  } else if (col == nb) {
-    v = INFINITY;                          // padding rows of the last tile never win
-  }
-  tiles[e] = v;
-}
-
-template <int KS>
-__global__ __launch_bounds__(256, 2) void k_lut_scan_mfma(const float* __restrict__ tiles, const float* __restrict__ obs,
-                                                          const float* __restrict__ w, int nb, int64_t ntile, int64_t M,
-                                                          int nslice, float* __restrict__ part_cost, int* __restrict__ part_tile) {
-  const int lane = threadIdx.x & 63;
-  const int64_t m0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (32 * LUT_TO);   // this wave's first observation
-  if (m0 >= M) return;                                                                 // (whole wave; no barrier below)
-  const int slice = blockIdx.y;
-  const int j = lane & 31, half = lane >> 5;
-  float bq[LUT_TO][KS];
-#pragma unroll
-  for (int blk = 0; blk < LUT_TO; ++blk) {
-    const int64_t m = m0 + blk * 32 + j;
-    const int64_t mc = m < M ? m : M - 1;
-#pragma unroll
-    for (int kk = 0; kk < KS; ++kk) {
-      const int col = 2 * kk + half;
-      bq[blk][kk] = col < nb ? -2.0f * (w ? w[col] : 1.0f) * obs[mc * nb + col] : (col == nb ? 1.0f : 0.0f);
-    }
-  }
-  const int64_t per = (ntile + nslice - 1) / nslice;
-  const int64_t t0 = per * slice;
-  const int64_t t1 = (t0 + per < ntile) ? t0 + per : ntile;
-  float best[LUT_TO];
-  int bt[LUT_TO];
-#pragma unroll
-  for (int blk = 0; blk < LUT_TO; ++blk) {
-    best[blk] = INFINITY;
-    bt[blk] = -1;
-  }
-  if (t0 < t1) {
-    const float* __restrict__ ap = tiles + t0 * (KS * 64) + lane;
-    float a[KS];
-#pragma unroll
-    for (int kk = 0; kk < KS; ++kk) a[kk] = ap[kk * 64];
-    for (int64_t t = t0; t < t1; ++t) {
-      if (t + 1 < t1) ap += KS * 64;                   // next tile's operands in flight during this tile's MFMAs
-      float an[KS];
-#pragma unroll
-      for (int kk = 0; kk < KS; ++kk) an[kk] = ap[kk * 64];
-#pragma unroll
-      for (int blk = 0; blk < LUT_TO; ++blk) {
-        spart_f16v acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], bq[blk][kk], acc, 0, 0, 0);
-        float mn = __builtin_fminf(__builtin_fminf(acc[0], acc[1]), acc[2]);
-#pragma unroll
-        for (int r = 3; r < 15; r += 2) mn = __builtin_fminf(__builtin_fminf(mn, acc[r]), acc[r + 1]);
-        mn = __builtin_fminf(mn, acc[15]);
-        if (mn < best[blk]) {                          // strict: an equal value in a later tile does not replace it
-          best[blk] = mn;
-          bt[blk] = (int)(t - t0);
-        }
-      }
-#pragma unroll
-      for (int kk = 0; kk < KS; ++kk) a[kk] = an[kk];
-    }
-  }
-#pragma unroll
-  for (int blk = 0; blk < LUT_TO; ++blk) {
-    const int64_t m = m0 + blk * 32 + j;
-    if (m < M) {
-      const int64_t o = ((int64_t)slice * 2 + half) * M + m;
-      part_cost[o] = best[blk];
-      part_tile[o] = bt[blk] < 0 ? -1 : (int)(t0 + bt[blk]);
-    }
-  }
-}
-
-// minimum over the (slice, lane-group) partial results, then the row inside the winning ROWS-row tile by the directly
-// evaluated cost sum_j w_j (x_j - y_j)^2 (which is also the cost that is reported): ascending + strict '<' = ties to
-// the lowest row index
-template <typename T, int ROWS>
-__global__ __launch_bounds__(256) void k_lut_reduce_tiles(const T* __restrict__ part_cost, const int* __restrict__ part_tile,
-                                                          const T* __restrict__ lut, const T* __restrict__ obs,
-                                                          const T* __restrict__ w, int nb, int64_t B, int64_t M, int npart,
-                                                          int64_t* __restrict__ best_idx, T* __restrict__ best_cost) {
-  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= M) return;
-  T best = INFINITY;
-  int bt = -1;
-  for (int p = 0; p < npart; ++p) {
-    const T c = part_cost[(int64_t)p * M + m];
-    const int t = part_tile[(int64_t)p * M + m];
-    if (t >= 0 && (c < best || (c == best && t < bt))) {
-      best = c;
-      bt = t;
-    }
-  }
-  int64_t bi = -1;
-  T bc = INFINITY;
-  if (bt >= 0) {
-    const int64_t r0 = (int64_t)bt * ROWS, r1 = (r0 + ROWS < B) ? r0 + ROWS : B;
-    for (int64_t r = r0; r < r1; ++r) {
-      T c = T(0);
-      for (int j = 0; j < nb; ++j) {
-        const T d = lut[r * nb + j] - obs[m * nb + j];
-        c += (w ? w[j] : T(1)) * d * d;
-      }
-      if (c < bc) {
-        bc = c;
-        bi = r;
-      }
-    }
-  }
-  best_idx[m] = bi;
-  best_cost[m] = bc;
-}
-
-// float64: the same scan on v_mfma_f64_16x16x4_f64 (K steps of 4, 16 x 16 tiles, four accumulator values per lane: lane l
-// holds four LUT rows of observation l % 16; the four lane groups l / 16 keep separate partial minima).
-typedef double spart_d4v __attribute__((ext_vector_type(4)));
-
-template <int KS>
-__global__ __launch_bounds__(256) void k_lut_prep_mfma64(const double* __restrict__ lut, const double* __restrict__ w, int nb,
-                                                         int64_t B, int64_t ntile, double* __restrict__ tiles) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= ntile * KS * 64) return;
-  const int lane = (int)(e & 63), kk = (int)((e >> 6) % KS);
-  const int64_t t = (e >> 6) / KS;
-  const int64_t row = t * 16 + (lane & 15);
-  const int col = 4 * kk + (lane >> 4);
-  double v = 0.0;
-  if (row < B) {
-    if (col < nb) {
-      v = lut[row * nb + col];
-    } else if (col == nb) {
-      for (int j = 0; j < nb; ++j) {
-        const double x = lut[row * nb + j];
-        v += (w ? w[j] : 1.0) * x * x;
-      }
-    }
-  } else if (col == nb) {
-    v = INFINITY;
-  }
-  tiles[e] = v;
-}
-
-template <int KS, int TO>
-__global__ __launch_bounds__(256, 2) void k_lut_scan_mfma64(const double* __restrict__ tiles, const double* __restrict__ obs,
-                                                            const double* __restrict__ w, int nb, int64_t ntile, int64_t M,
-                                                            int nslice, double* __restrict__ part_cost, int* __restrict__ part_tile) {
-  const int lane = threadIdx.x & 63;
-  const int64_t m0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (16 * TO);
-  if (m0 >= M) return;
-  const int slice = blockIdx.y;
-  const int j = lane & 15, q = lane >> 4;
-  double bq[TO][KS];
-#pragma unroll
-  for (int blk = 0; blk < TO; ++blk) {
-    const int64_t m = m0 + blk * 16 + j;
-    const int64_t mc = m < M ? m : M - 1;
-#pragma unroll
-    for (int kk = 0; kk < KS; ++kk) {
-      const int col = 4 * kk + q;
-      bq[blk][kk] = col < nb ? -2.0 * (w ? w[col] : 1.0) * obs[mc * nb + col] : (col == nb ? 1.0 : 0.0);
-    }
-  }
-  const int64_t per = (ntile + nslice - 1) / nslice;
-  const int64_t t0 = per * slice;
-  const int64_t t1 = (t0 + per < ntile) ? t0 + per : ntile;
-  double best[TO];
-  int bt[TO];
-#pragma unroll
-  for (int blk = 0; blk < TO; ++blk) {
-    best[blk] = INFINITY;
-    bt[blk] = -1;
-  }
-  if (t0 < t1) {
-    const double* __restrict__ ap = tiles + t0 * (KS * 64) + lane;
-    double a[KS];
-#pragma unroll
-    for (int kk = 0; kk < KS; ++kk) a[kk] = ap[kk * 64];
-    for (int64_t t = t0; t < t1; ++t) {
-      if (t + 1 < t1) ap += KS * 64;
-      double an[KS];
-#pragma unroll
-      for (int kk = 0; kk < KS; ++kk) an[kk] = ap[kk * 64];
-#pragma unroll
-      for (int blk = 0; blk < TO; ++blk) {
-        spart_d4v acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], bq[blk][kk], acc, 0, 0, 0);
-        const double mn = __builtin_fmin(__builtin_fmin(acc[0], acc[1]), __builtin_fmin(acc[2], acc[3]));
-        if (mn < best[blk]) {
-          best[blk] = mn;
-          bt[blk] = (int)(t - t0);
-        }
-      }
-#pragma unroll
-      for (int kk = 0; kk < KS; ++kk) a[kk] = an[kk];
-    }
-  }
-#pragma unroll
-  for (int blk = 0; blk < TO; ++blk) {
-    const int64_t m = m0 + blk * 16 + j;
-    if (m < M) {
-      const int64_t o = ((int64_t)slice * 4 + q) * M + m;
-      part_cost[o] = best[blk];
-      part_tile[o] = bt[blk] < 0 ? -1 : (int)(t0 + bt[blk]);
-    }
-  }
-}
-
 }  // namespace spart

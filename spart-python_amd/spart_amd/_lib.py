@@ -52,6 +52,8 @@ SIGNATURES = {
     "spart_lut_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int64]),
     "spart_lut_nearest": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int64, ctypes.c_int, vp, ctypes.c_int64, vp, vp, vp, vp,
                                          vp, ctypes.c_size_t, vp]),
+    "spart_lut_stats": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int64, vp,
+                                       ctypes.POINTER(ctypes.c_int64), c_dp]),
     "spart_profile_enable": (ctypes.c_int, [vp, ctypes.c_int]),
     "spart_profile_read": (ctypes.c_int, [vp, c_dp, ctypes.POINTER(ctypes.c_int)]),
     "spart_profile_read_stages": (ctypes.c_int, [vp, c_dp, ctypes.POINTER(ctypes.c_int)]),
@@ -91,12 +93,30 @@ def load(path=None):
     import torch  # noqa: F401
 
     in_tree = path == os.path.abspath(LIB_PATH)
+    want = None
     if in_tree:
-        b = _build_module()
-        want, have = expected_build_id(), b.binary_id(path)
-        if have != want:
-            try:    # the .so is a build artefact (git-ignored): compile it when it is missing or stale and hipcc is around
-                b.build(verbose=True)
+        try:
+            b = _build_module()
+            want = expected_build_id()
+        except OSError:
+            # a deployment that ships the prebuilt library without csrc/: nothing to compare the binary with
+            b, want = None, None
+            if not os.path.exists(path):
+                raise RuntimeError(f"{path} is missing and the kernel sources to build it from are not installed. "
+                                   "spart_amd has no CPU fallback.") from None
+        have = b.binary_id(path) if b is not None else None
+        if want is not None and have != want:
+            # the .so is a build artefact (git-ignored): compile it when it is missing or stale and hipcc is around.  Several
+            # ranks may get here at once: one compiles (file lock), the others wait and find the library current.
+            try:
+                import fcntl
+                with open(path + ".lock", "w") as lock:
+                    fcntl.flock(lock, fcntl.LOCK_EX)
+                    try:
+                        if b.binary_id(path) != want:
+                            b.build(verbose=True)
+                    finally:
+                        fcntl.flock(lock, fcntl.LOCK_UN)
             except Exception as e:      # noqa: BLE001
                 if os.path.exists(path):
                     raise RuntimeError(f"{path} was built from other sources (build id {have}, sources {want}) and could "
@@ -112,7 +132,7 @@ def load(path=None):
         fn = getattr(lib, name)  # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args
-    if in_tree and lib.spart_build_id().decode() != want:      # (what the loaded code says, not what the file's bytes said)
+    if in_tree and want is not None and lib.spart_build_id().decode() != want:      # (what the loaded code says, not what the file's bytes said)
         raise RuntimeError(f"{path} reports build id {lib.spart_build_id().decode()}, the sources next to it are {want}")
     _libs[path] = lib
     return lib

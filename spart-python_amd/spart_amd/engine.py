@@ -354,9 +354,12 @@ class Engine:
         replay.graph = g
         return replay
 
-    def lut_nearest(self, lut, obs, weights=None, dtype="float32"):
-        """LUT inversion: for each row of obs (M, nb) the index of the closest row of lut (B, nb) under the
-        weighted squared distance, and that distance.  -> (idx (M,) int64 tensor, cost (M,) tensor)"""
+    def lut_nearest(self, lut, obs, weights=None, dtype="float32", stats=False):
+        """LUT inversion: for each row of obs (M, nb) the index of THE closest row of lut (B, nb) under the weighted squared
+        distance ``c = sum_j (w_j * d_j) * d_j``, ``d = lut - obs`` (sequential, rounded to ``dtype``, no FMA), lowest index on
+        ties, and that distance -- bit-exact against a brute-force loop (include/spart_hip.h: spart_lut_nearest).
+        -> (idx (M,) int64 tensor, cost (M,) tensor); with ``stats=True`` also a dict with the number of observations that
+        took the brute-force path and the scale Nmax of the rounding bound (spart_lut_stats; synchronises)."""
         torch = self.torch
         dt = DTYPES[dtype]
         td = self._tdtype(dt)
@@ -378,7 +381,14 @@ class Engine:
                                         w.data_ptr() if w is not None else None, idx.data_ptr(), cost.data_ptr(),
                                         ws.data_ptr(), ctypes.c_size_t(ws.numel()), self._stream())
         _lib.check(self.lib, self.ctx, rc)
-        return idx, cost
+        if not stats:
+            return idx, cost
+        nbf, nmax = ctypes.c_int64(0), ctypes.c_double(0.0)
+        if M > 0:
+            torch.cuda.current_stream(self.device).synchronize()
+            _lib.check(self.lib, self.ctx, self.lib.spart_lut_stats(self.ctx, dt, B, nb, M, ws.data_ptr(), ctypes.byref(nbf),
+                                                                    ctypes.byref(nmax)))
+        return idx, cost, {"brute_force": int(nbf.value), "nmax": float(nmax.value)}
 
     def profile(self, max_calls):
         """bracket the band kernel of the next ``max_calls`` run() calls with HIP events (0 = off)."""

@@ -3,6 +3,7 @@ reference's golden vectors.  Tolerances: north_star's 1e-6 rel (fp64) / 1e-4 rel
 sensor columns; spectra use the same relative bound with an absolute floor matching the
 reference's own unit-test precision (assert_almost_equal: 1.5e-7 leaf, 1.5e-6 canopy)."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -730,33 +731,69 @@ def test_lut_on_disk_parquet_leg(golden, tmp_path, torch_mod):
         assert rel_err(tab, g[f"lhs_full/Sentinel2A-MSI/{k}"], COLFLOOR) < 1e-6, k
 
 
+def _lut_brute_force():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import lut_brute_force
+    return lut_brute_force
+
+
 @pytest.mark.parametrize("dtype,nb", [("float32", 13), ("float64", 13), ("float32", 6), ("float32", 21), ("float32", 15),
-                                      ("float32", 31), ("float32", 1), ("float64", 31)])
+                                      ("float32", 31), ("float32", 1), ("float32", 3), ("float64", 31), ("float64", 1),
+                                      ("float64", 3)])
 def test_lut_inversion_matches_brute_force(dtype, nb, torch_mod):
-    """spart_lut_nearest against a numpy brute-force search (weighted and unweighted, ragged sizes, NaN rows)."""
+    """spart_lut_nearest returns THE argmin: index and cost bit-equal to a numpy brute force that evaluates the cost as the
+    header defines it (sequential, in the call's dtype, no FMA; first index on ties -- the reference's np.argmin rule,
+    SPART.py:381-387).  Weighted and unweighted, ragged sizes, a NaN row, exact members, every compiled K incl. nb = 1."""
     from spart_amd import get_engine
+    bf = _lut_brute_force()
     rng = np.random.default_rng(nb)
     B, M = 20_011, 777
-    lut = rng.uniform(0.0, 0.6, (B, nb))
-    lut[17] = np.nan                                  # a NaN row must never win
-    obs = lut[rng.integers(18, B, M)] + rng.normal(0, 0.01, (M, nb))
-    obs[:5] = lut[100:105]                            # exact members: cost 0, index recovered
-    eng = get_engine(None, 0)
     npdt = np.float32 if dtype == "float32" else np.float64
-    for w in (None, rng.uniform(0.5, 2.0, nb)):
-        idx, cost = eng.lut_nearest(lut.astype(npdt), obs.astype(npdt), w, dtype)
-        idx, cost = idx.cpu().numpy(), cost.double().cpu().numpy()
-        L, O = lut.astype(npdt).astype(np.float64), obs.astype(npdt).astype(np.float64)
-        ww = np.ones(nb) if w is None else w.astype(npdt).astype(np.float64)
-        d = np.stack([np.nansum(ww * (L - O[m]) ** 2, axis=1) + np.where(np.isnan(L[:, 0]), np.inf, 0) for m in range(M)])
-        true_idx, true_cost = d.argmin(axis=1), d.min(axis=1)
-        tol = 1e-6 if dtype == "float32" else 1e-12
-        assert np.all(d[np.arange(M), idx] <= true_cost + tol)            # the chosen row is a minimiser (ties aside)
-        if nb > 1:                                    # (one band: 20 000 rows 3e-5 apart, squared distances tie at the tolerance)
-            assert np.mean(idx == true_idx) > 0.999
-        assert np.max(np.abs(cost - true_cost)) < 10 * tol
-        if nb > 1 or dtype == "float64":              # exact members: the cost is recomputed from the row
-            assert list(idx[:5]) == [100, 101, 102, 103, 104] and np.all(cost[:5] == 0.0)
+    lut = rng.uniform(0.0, 0.6, (B, nb)).astype(npdt)
+    lut[17] = np.nan                                  # a NaN row must never win
+    obs = (lut[rng.integers(18, B, M)] + rng.normal(0, 0.01, (M, nb))).astype(npdt)
+    obs[:5] = lut[100:105]                            # exact members: cost 0
+    eng = get_engine(None, 0)
+    for w in (None, rng.uniform(0.5, 2.0, nb).astype(npdt)):
+        idx, cost, st = eng.lut_nearest(lut, obs, w, dtype, stats=True)
+        idx, cost = idx.cpu().numpy(), cost.cpu().numpy()
+        true_idx, true_cost = bf.brute_force_numpy(lut, obs, w)
+        assert np.array_equal(idx, true_idx), (dtype, nb, int(np.sum(idx != true_idx)))
+        assert np.array_equal(cost, true_cost)
+        assert np.all(cost[:5] == 0.0) and np.all(idx >= 0) and 17 not in idx
+        assert 0 <= st["brute_force"] <= M and np.isfinite(st["nmax"])
+
+
+@pytest.mark.parametrize("dtype,nb", [("float32", 3), ("float32", 6), ("float32", 13), ("float32", 21), ("float64", 6)])
+def test_lut_inversion_exact_on_a_correlated_lut(dtype, nb, torch_mod):
+    """The hard case for a GEMM-form search: a 400 000-row LUT whose nb bands are smooth functions of 4 latent parameters
+    (rows lie on a 4-dimensional sheet, neighbours are close) and observations = rows with 2 % noise.  In float32 the
+    cancelling form |x|^2 - 2 x.y alone picks a wrong row for ~1 % of such observations at nb <= 6; the result here must be
+    the exact argmin for every one of them (checked against an eager-torch brute force of the defined cost), and the filter
+    must have done its job: only a small fraction may have needed the brute-force kernel."""
+    from spart_amd import get_engine
+    bf = _lut_brute_force()
+    torch = torch_mod
+    rng = np.random.default_rng(100 + nb)
+    B, M = 400_000, 3000
+    z = rng.uniform(0, 1, (B, 4))
+    A, C = rng.normal(0, 1.5, (4, nb)), rng.normal(0, 1.0, (4, nb))
+    npdt = np.float32 if dtype == "float32" else np.float64
+    lut = (0.03 + 0.5 / (1.0 + np.exp(-(z @ A + (z * z) @ C - 1.0)))).astype(npdt)
+    pick = rng.integers(0, B, M)
+    obs = (lut[pick] * (1.0 + rng.normal(0, 0.02, (M, nb)))).astype(npdt)
+    obs[:50] = lut[pick[:50]]                         # some exact members
+    w = rng.uniform(0.5, 2.0, nb).astype(npdt)
+    eng = get_engine(None, 0)
+    L, O = torch.as_tensor(lut, device="cuda:0"), torch.as_tensor(obs, device="cuda:0")
+    for ww in (None, torch.as_tensor(w, device="cuda:0")):
+        idx, cost, st = eng.lut_nearest(L, O, ww, dtype, stats=True)
+        true_idx, true_cost = bf.brute_force_torch(L, O, ww)
+        assert torch.equal(idx, true_idx), (dtype, nb, int((idx != true_idx).sum()))
+        assert torch.equal(cost, true_cost)
+        assert float(cost[:50].max()) == 0.0
+        if nb >= 6:                                   # (nb = 3: the rows fill a volume densely, many tiles tie within the bound)
+            assert st["brute_force"] <= 0.05 * M, st  # the filter leaves the brute force a few per cent at most
 
 
 def test_caller_owned_spectrum_buffers(torch_mod):
@@ -799,21 +836,25 @@ def test_fast_prelude_option_stays_inside_the_contract(golden, torch_mod):
 
 def test_lut_inversion_small_and_tied(torch_mod):
     """Sizes below one MFMA tile / one observation block, duplicate rows (ties go to the lowest row index, also across
-    32-row tiles and across slices), an all-NaN LUT and a NaN observation (index -1, cost inf)."""
+    32-row tiles and across slices), mixed-sign weights, an all-NaN LUT and a NaN observation (index -1, cost inf); the
+    duplicated rows force the brute-force kernel, which the statistics must show."""
     from spart_amd import get_engine
+    bf = _lut_brute_force()
     eng = get_engine(None, 0)
     rng = np.random.default_rng(5)
-    for B, M in ((1, 1), (20, 3), (33, 130), (4099, 1), (70_000, 5)):
-        lut = rng.uniform(0.0, 0.6, (B, 13)).astype(np.float32)
-        obs = lut[rng.integers(0, B, M)] + rng.normal(0, 0.01, (M, 13)).astype(np.float32)
-        idx, cost = eng.lut_nearest(lut, obs)
-        d = ((lut.astype(np.float64)[None] - obs.astype(np.float64)[:, None]) ** 2).sum(-1)
-        assert np.all(d[np.arange(M), idx.cpu().numpy()] <= d.min(axis=1) + 1e-6), (B, M)
+    for dtype, npdt in (("float32", np.float32), ("float64", np.float64)):
+        for B, M in ((1, 1), (20, 3), (33, 130), (4099, 1), (70_000, 5)):
+            lut = rng.uniform(0.0, 0.6, (B, 13)).astype(npdt)
+            obs = (lut[rng.integers(0, B, M)] + rng.normal(0, 0.01, (M, 13))).astype(npdt)
+            for w in (None, rng.uniform(-0.2, 2.0, 13).astype(npdt)):
+                idx, cost = eng.lut_nearest(lut, obs, w, dtype)
+                ti, tc = bf.brute_force_numpy(lut, obs, w)
+                assert np.array_equal(idx.cpu().numpy(), ti) and np.array_equal(cost.cpu().numpy(), tc), (dtype, B, M)
     lut = rng.uniform(0.0, 0.6, (5000, 13)).astype(np.float32)
     lut[[40, 700, 4100]] = lut[7]                     # the same row in three other tiles
     lut[3] = lut[2]
     for dtype in ("float32", "float64"):
-        idx, cost = eng.lut_nearest(lut, lut[[7, 700, 3, 2]], dtype=dtype)
+        idx, cost, st = eng.lut_nearest(lut, lut[[7, 700, 3, 2]], dtype=dtype, stats=True)
         assert idx.cpu().tolist() == [7, 7, 2, 2] and float(cost.abs().max()) == 0.0, dtype
         obs = lut[:3].copy()
         obs[1, 4] = np.nan
@@ -821,21 +862,41 @@ def test_lut_inversion_small_and_tied(torch_mod):
         assert idx.cpu().tolist() == [0, -1, 2] and np.isinf(cost.cpu().numpy()[1]), dtype
         idx, cost = eng.lut_nearest(np.full((100, 13), np.nan, dtype=np.float32), lut[:2], dtype=dtype)
         assert idx.cpu().tolist() == [-1, -1] and bool(np.isinf(cost.cpu().numpy()).all()), dtype
+        big = lut.copy()
+        big[5] = np.inf                               # an infinite row and a huge one never win, nothing overflows the filter
+        big[6] = 1e30
+        idx, cost = eng.lut_nearest(big, lut[[5, 6, 8]], dtype=dtype)
+        ti, tc = bf.brute_force_numpy(big.astype(np.float32 if dtype == "float32" else np.float64),
+                                      lut[[5, 6, 8]].astype(np.float32 if dtype == "float32" else np.float64))
+        assert np.array_equal(idx.cpu().numpy(), ti) and np.array_equal(cost.cpu().numpy(), tc), dtype
+    # a LUT of ONE repeated row (more tiles than slices): every tile ties, every observation takes the brute force, row 0 wins
+    same = np.tile(lut[9], (40_000, 1))
+    idx, cost, st = eng.lut_nearest(same, lut[:70], stats=True)
+    assert idx.cpu().tolist() == [0] * 70 and st["brute_force"] == 70
 
 
 def test_lut_inversion_recovers_parameters(torch_mod):
-    """End to end: build a LUT with the evaluator, invert noisy copies of some of its rows."""
+    """End to end: build a LUT with the evaluator, invert noisy copies of some of its rows; exact members come back as
+    themselves with cost 0 in both dtypes (round 3's float32 search returned a few-ulp-of-|x|^2 neighbour instead)."""
     from spart_amd import get_engine, workloads
+    bf = _lut_brute_force()
     eng = get_engine("Sentinel2A-MSI", 0)
     P = workloads.lhs_params(200_000, "full", seed=33)
     out = eng.run(torch_mod.as_tensor(P.T.copy(), device="cuda:0"), "float32")
-    lut = out["R_TOA"].clone()
-    pick = torch_mod.arange(0, 200_000, 997, device="cuda:0")
-    idx, cost = eng.lut_nearest(lut, lut[pick])
-    # float32 evaluates |x|^2 - 2 x.y + |y|^2, so an exact member comes back with a cost of a few ulp of |x|^2
-    assert float((idx == pick).double().mean()) > 0.99 and float(cost.max()) < 1e-5
-    idx64, cost64 = eng.lut_nearest(lut.double(), lut[pick].double(), dtype="float64")
-    assert torch_mod.equal(idx64, pick) and float(cost64.max()) < 1e-14
+    for name in ("R_TOA", "L_TOA"):                    # reflectance scale and radiance scale
+        lut = out[name].clone()
+        pick = torch_mod.arange(0, 200_000, 997, device="cuda:0")
+        idx, cost = eng.lut_nearest(lut, lut[pick])
+        ti, tc = bf.brute_force_torch(lut, lut[pick])
+        assert torch_mod.equal(idx, ti) and torch_mod.equal(cost, tc) and float(cost.max()) == 0.0
+        assert float((idx == pick).double().mean()) > 0.999          # (duplicate rows aside, a member is its own nearest row)
+        noisy = lut[pick] * (1 + 0.03 * torch_mod.randn((pick.numel(), lut.shape[1]), device="cuda:0", generator=torch_mod.Generator("cuda:0").manual_seed(1)))
+        idx, cost = eng.lut_nearest(lut, noisy)
+        ti, tc = bf.brute_force_torch(lut, noisy)
+        assert torch_mod.equal(idx, ti) and torch_mod.equal(cost, tc)
+        idx64, cost64 = eng.lut_nearest(lut.double(), noisy.double(), dtype="float64")
+        ti, tc = bf.brute_force_torch(lut.double(), noisy.double())
+        assert torch_mod.equal(idx64, ti) and torch_mod.equal(cost64, tc)
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
