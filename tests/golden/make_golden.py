@@ -20,6 +20,11 @@ Files
                  starts above 400 nm, an ascending file) (bsm.py:201-226)
   grids.npz      the reference's full unit-test grids (6480 PROSPECT + 8100 SAILH cases): 16 probe bands + the all-band mean of
                  every spectrum (python tests/golden/make_golden.py grids; ~5 min on 8 processes)
+  s2_f64.npz     Sentinel-2A/B with the reference's OWN arithmetic but its SMAC coefficients up-cast to float64 IN THE HARNESS
+                 (the S2 pickles store them as float32, so the reference's outputs carry ~1e-7 of float32 noise that every
+                 comparison with smac.npz / e2e.npz / edge.npz has to allow for): the 12 SMAC rows of smac.npz, defaults,
+                 PRO, the 256 config-4 rows, the 64 config-5 rows and the 128 edge rows.  Pins the ALGEBRA of smac_band on
+                 the headline sensors at 1e-12 / 1e-10 (SPART.py:228, smac.py:44-92, 100-211)
   edge.npz       128 rows of tools/edge_sweep.py's widened ranges with edge values (LAI 0 / 1e-4 / 10, dry soil, N = 1,
                  zero pigments, exact hot spot, grazing angles, PRO leaves), Sentinel2A: P + R_TOC / R_TOA / L_TOA
 """
@@ -167,13 +172,21 @@ def gen_smac():
     print("smac done")
 
 
+def coef_f64(coef):
+    """the reference's SMAC_coef dict with every array up-cast to float64 (a new dict: the reference's data are untouched)"""
+    return {k: np.asarray(v).astype(np.float64) for k, v in coef.items()}
+
+
 def run_row(args):
-    row, sensor = args
+    row, sensor = args[0], args[1]
+    upcast = len(args) > 2 and args[2]
     leaf, soil, can, ang, atm, doy = row[0:9], row[9:15], row[15:19], row[19:22], row[22:26], row[26]
     with redirect_stdout(io.StringIO()):
         sp = SPART.SPART(SoilParameters(*soil), LeafBiology(*leaf[:7], PROT=leaf[7], CBC=leaf[8]),
                          CanopyStructure(*can), AtmosphericProperties(atm[0], atm[1], atm[2], Pa=atm[3]),
                          Angles(*ang), sensor, doy if doy != int(doy) else int(doy))
+        if upcast:          # on the OBJECT (SPART.py:95, read at SPART.py:228): float64 coefficients, same code
+            sp.sensorinfo["SMAC_coef"] = coef_f64(sp.sensorinfo["SMAC_coef"])
         df = sp.run(debug=True)
     probes = [0, 150, 400, 1000, 1600, 2000, 2100]   # 400, 550, 800, 1400, 2000, 2400 nm, first thermal
     extra = np.concatenate([sp.leafopt.refl[probes, 0], sp.leafopt.tran[probes, 0], sp.soilopt.refl[probes, 0],
@@ -206,6 +219,47 @@ def gen_e2e():
                 out[f"{name}/{k}"] = np.array([r[j] for r in res])
             print(name, P.shape, flush=True)
     np.savez_compressed(os.path.join(HERE, "e2e.npz"), **out)
+
+
+def gen_s2f64():
+    """Sentinel-2 with float64 SMAC coefficients (see the file list above): same inputs as smac.npz / e2e.npz / edge.npz."""
+    import warnings
+    import edge_sweep
+    warnings.filterwarnings("ignore")
+    out = {}
+    sm = np.load(os.path.join(HERE, "smac.npz"))
+    for s in ("Sentinel2A-MSI", "Sentinel2B-MSI"):
+        si = SPART.load_sensor_info(s)
+        coef = coef_f64(si["SMAC_coef"])
+        assert all(v.dtype == np.float32 for v in si["SMAC_coef"].values())      # (what this fixture is about)
+        ang, atm = sm[f"{s}/angles"], sm[f"{s}/atm"]
+        nb = si["wl_smac"].shape[0]
+        res = {f: [] for f in SMAC_FIELDS}
+        for a, t in zip(ang, atm):
+            ao = SMAC(Angles(*a), AtmosphericProperties(t[0], t[1], t[2], Pa=t[3]), coef)
+            for f in SMAC_FIELDS:
+                v = np.asarray(getattr(ao, f))
+                assert v.dtype == np.float64
+                res[f].append(np.broadcast_to(v, (1, nb))[0].copy())
+        out[f"smac/{s}/angles"] = ang; out[f"smac/{s}/atm"] = atm
+        for f in SMAC_FIELDS:
+            out[f"smac/{s}/{f}"] = np.array(res[f])
+    e2e = np.load(os.path.join(HERE, "e2e.npz"))
+    edge = np.load(os.path.join(HERE, "edge.npz"))
+    groups = [(n, n.split("/")[1], e2e[n + "/P"]) for n in ("defaults/Sentinel2A-MSI", "defaults/Sentinel2B-MSI", "pro/Sentinel2B-MSI",
+                                                            "lhs_full/Sentinel2A-MSI", "lhs_pro/Sentinel2B-MSI")]
+    groups.append(("edge/" + edge_sweep.SENSOR, edge_sweep.SENSOR, edge["P"]))
+    with np.errstate(all="ignore"), Pool(8) as pool:
+        for name, sensor, P in groups:
+            res = pool.map(run_row, [(r, sensor, True) for r in P], chunksize=4)
+            out[f"{name}/P"] = P
+            for j, k in enumerate(["R_TOC", "R_TOA", "L_TOA", "rsoil", "La"]):
+                out[f"{name}/{k}"] = np.array([r[j] for r in res])
+            ref32 = e2e[name + "/R_TOA"] if not name.startswith("edge") else edge["R_TOA"]
+            with np.errstate(all="ignore"):
+                dev = np.nanmax(np.abs(out[f"{name}/R_TOA"] - ref32) / np.maximum(np.abs(ref32), 1e-6))
+            print(name, P.shape, "R_TOA moved by up to %.2e against the float32-coefficient rows" % dev, flush=True)
+    np.savez_compressed(os.path.join(HERE, "s2_f64.npz"), **out)
 
 
 def gen_rdry():
@@ -362,6 +416,6 @@ def gen_grids():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["prospect", "bsm", "sailh", "smac", "e2e", "rdry", "jpl", "edge"]
+    which = sys.argv[1:] or ["prospect", "bsm", "sailh", "smac", "e2e", "rdry", "jpl", "edge", "s2f64"]
     for w in which:
         globals()["gen_" + w]()

@@ -977,6 +977,41 @@ def test_edge_rows_golden(golden, torch_mod):
         assert rel_err(o32[k].cpu().numpy()[phys], g[k][phys], COLFLOOR) < 1e-4, k
 
 
+def test_sentinel2_float64_coefficient_pins(golden, torch_mod):
+    """Sentinel-2A/B against the reference run with its float32 SMAC coefficients up-cast to float64 in the harness
+    (tests/golden/s2_f64.npz, make_golden.py gen_s2f64; SPART.py:228, smac.py:44-92): the float32-storage noise that forces
+    2e-6 / 5e-7 on every other Sentinel-2 comparison is gone, so the HIP float64 path is held to 1e-9 on the nine SMAC
+    outputs and 1e-8 on the columns (survey metric, floor 1e-6) for the defaults, PRO, the 256 config-4 rows and the 64
+    config-5 rows, and to north_star's 1e-6 on a 1e-6 floor for R_TOA / L_TOA of the 128 edge rows (edge.npz needs floor 1e-2)."""
+    from spart_amd import get_engine
+    from spart_amd.engine import SMAC_FIELDS
+    g = golden["s2_f64"]
+    worst = {}
+    for sensor in ("Sentinel2A-MSI", "Sentinel2B-MSI"):
+        eng = get_engine(sensor, 0)
+        out = eng.smac(list(g[f"smac/{sensor}/angles"].T), list(g[f"smac/{sensor}/atm"].T))
+        for f in SMAC_FIELDS:
+            e = rel_err(out[f].cpu().numpy(), g[f"smac/{sensor}/{f}"], COLFLOOR)
+            worst[("smac", sensor)] = max(worst.get(("smac", sensor), 0.0), e)
+            assert e < 1e-9, (sensor, f, e)
+    for name in ("defaults/Sentinel2A-MSI", "defaults/Sentinel2B-MSI", "pro/Sentinel2B-MSI", "lhs_full/Sentinel2A-MSI",
+                 "lhs_pro/Sentinel2B-MSI"):
+        eng = get_engine(name.split("/")[1], 0)
+        out = eng.run(torch_mod.as_tensor(g[name + "/P"].T.copy(), device="cuda:0"), "float64", materialize=("rsoil", "La"))
+        for k in ("R_TOC", "R_TOA", "L_TOA", "rsoil", "La"):
+            e = rel_err(out[k].cpu().numpy(), g[f"{name}/{k}"], COLFLOOR)
+            worst[name] = max(worst.get(name, 0.0), e)
+            assert e < 1e-8, (name, k, e)
+    P = g["edge/Sentinel2A-MSI/P"]
+    keep = (P[:, 1] + P[:, 2]) > 0                     # (test_edge_rows_golden: without water or dry matter the reference divides by zero)
+    out = get_engine("Sentinel2A-MSI", 0).run(torch_mod.as_tensor(P.T.copy(), device="cuda:0"), "float64")
+    for k in ("R_TOC", "R_TOA", "L_TOA"):
+        e = rel_err(out[k].cpu().numpy()[keep], g[f"edge/Sentinel2A-MSI/{k}"][keep], COLFLOOR)
+        worst["edge/" + k] = e
+        assert e < 1e-6, (k, e)
+    print({str(k): f"{v:.1e}" for k, v in worst.items()})
+
+
 MAT_FIELDS = ("leaf_refl", "leaf_tran", "leaf_kchl", "soil_refl", "soil_refl_dry", "rso", "rdo", "rsd", "rdd")
 
 
