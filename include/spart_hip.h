@@ -18,9 +18,14 @@
  *   - spectra and result columns are row-major (B, nbands), band-contiguous, in `dtype`; the row pitch of the
  *     2162- / 2001-wide spectrum arrays is the row width unless spart_ctx_set_row_pitch says otherwise;
  *   - `stream` is a hipStream_t (NULL = default stream); calls are asynchronous on it (spart_run_batch may run some
- *     of its kernels on a side stream the context owns; it joins them back into `stream` before it returns, so the
- *     caller sees plain stream semantics, HIP-graph capture included).  Calls on ONE context must not be issued from
- *     several host threads at once (one context per thread otherwise);
+ *     of its kernels on a side stream the context owns -- one per caller stream -- and joins them back into `stream`
+ *     before it returns, so the caller sees plain stream semantics, HIP-graph capture included);
+ *   - a context is THREAD-SAFE: its tables are immutable after creation and the little per-call state it has (side
+ *     streams, events) is guarded, so any number of host threads may call into one context on any streams.  Calls
+ *     that run concurrently on the GPU (different streams) need different workspaces; if two streams do pass the
+ *     same workspace, the later call is ordered after the earlier one (hipStreamWaitEvent on its completion) -- slow,
+ *     never a race -- or fails with SPART_ERR_INVALID when that order cannot be expressed (e.g. across a stream
+ *     capture).  HIP-graph REPLAYS are outside the library's view: a captured call's workspace belongs to its graph;
  *   - return value 0 = ok, <0 = error (spart_last_error gives the text).  Numerical trouble
  *     propagates as NaN/inf exactly like the reference (no clamping).
  */
@@ -112,7 +117,7 @@ typedef struct spart_materialize {
 
 int spart_ctx_create(spart_ctx **out, int device, const spart_tables *tables);
 int spart_ctx_destroy(spart_ctx *ctx);
-const char *spart_last_error(const spart_ctx *ctx); /* ctx may be NULL: last creation error */
+const char *spart_last_error(const spart_ctx *ctx); /* text of the last error raised ON THE CALLING THREAD (ctx may be NULL) */
 
 /* Identity of this binary: 12 hex digits over the kernel / ABI sources, compiler flags and math variant it was built
  * from (spart-python_amd/build.py: source_id).  The Python loader refuses a library whose id is not that of the

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -18,6 +19,20 @@
 #include "spart_lut.h"
 
 using namespace spart;
+
+struct SideLane {
+  hipStream_t caller = nullptr, side = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+};
+struct WsUse {
+  const char* base = nullptr;
+  size_t bytes = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t done = nullptr;
+  uint64_t stamp = 0;
+};
+constexpr size_t MAX_LANES = 32;     // caller streams with their own side stream (further streams run the columns in line)
+constexpr size_t MAX_WS_USES = 16;   // (workspace, stream) pairs remembered
 
 struct spart_ctx {
   int device = 0;
@@ -33,29 +48,39 @@ struct spart_ctx {
   double* coef = nullptr;    // (48, nb)
   double* econv = nullptr;   // (nb)
   std::vector<double> econv_host;
-  // the default float32 mode runs its float64 slot pass + sensor kernel on this side stream, beside the full-band
-  // kernel (fork / join with the two events below; spart_run_batch stays asynchronous on the caller's stream)
-  hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // Everything below is mutable per-call state, guarded by `mu`: an entry point holds it while it checks the workspace
+  // and issues its launches (microseconds; the GPU work itself stays asynchronous), so calls on ONE context may come from
+  // any number of host threads and streams.
+  std::mutex mu;
+  // The column kernels (float64 slot pass + sensor kernel) run on a side stream beside the full-band kernel (fork / join
+  // with two events; spart_run_batch stays asynchronous on the caller's stream).  One lane PER CALLER STREAM, created on
+  // first use: two caller streams never share a side stream or an event pair, and a stream under HIP-graph capture
+  // pulls only its own side stream into the capture.
+  bool side_enabled = true;
+  std::vector<SideLane> lanes;
+  // Last use of every workspace recently handed in: (range, stream, completion event).  A call that gets a workspace
+  // still owned by a call on ANOTHER stream is ordered after it (hipStreamWaitEvent), so sharing one workspace between
+  // streams is slow but never a race; if the order cannot be expressed the call fails with SPART_ERR_INVALID.
+  std::vector<WsUse> ws_uses;
+  uint64_t stamp = 0;
   // optional timing of the dominant kernel (k_bands): event pairs recorded on the caller's stream
   bool profile = false;
   std::vector<hipEvent_t> ev;   // NEV events per timed call (run_impl)
   size_t ev_used = 0;
   std::vector<char> ev_forked;  // per timed call: slot pass + sensor kernel ran on the side stream
-  mutable char err[512] = {0};
 };
 
 constexpr size_t NEV = 5;        // events per timed spart_run_batch call: 4 stage intervals
 
+// the text of the last error raised ON THE CALLING THREAD (spart_last_error): per thread, so that concurrent calls on one
+// context cannot garble each other's message
 static thread_local char g_err[512] = {0};
 
-static int fail(const spart_ctx* ctx, int code, const char* fmt, ...) {
-  char* dst = ctx ? ctx->err : g_err;
+static int fail(const spart_ctx*, int code, const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
-  vsnprintf(dst, 512, fmt, ap);
+  vsnprintf(g_err, 512, fmt, ap);
   va_end(ap);
-  if (ctx) std::snprintf(g_err, 512, "%s", dst);
   return code;
 }
 
@@ -113,6 +138,71 @@ struct DeviceGuard {
     if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
   }
 };
+
+// ---- per-call state of a context (all under ctx->mu)
+// the side stream + event pair of caller stream `st`, created on first use; nullptr = run the columns in line
+SideLane* lane_for(spart_ctx* ctx, hipStream_t st) {
+  if (!ctx->side_enabled) return nullptr;
+  for (SideLane& l : ctx->lanes)
+    if (l.caller == st) return &l;
+  if (ctx->lanes.size() >= MAX_LANES) return nullptr;
+  SideLane l;
+  l.caller = st;
+  if (hipStreamCreateWithFlags(&l.side, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&l.fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&l.join, hipEventDisableTiming) != hipSuccess) {
+    (void)hipGetLastError();
+    if (l.fork) (void)hipEventDestroy(l.fork);
+    if (l.join) (void)hipEventDestroy(l.join);
+    if (l.side) (void)hipStreamDestroy(l.side);
+    return nullptr;
+  }
+  ctx->lanes.push_back(l);
+  return &ctx->lanes.back();
+}
+
+// Before a call's first launch: order it after every call that used an overlapping workspace range on ANOTHER stream.
+int ws_acquire(spart_ctx* ctx, const char* base, size_t bytes, hipStream_t st, const char* who) {
+  for (const WsUse& u : ctx->ws_uses) {
+    if (u.stream == st || base >= u.base + u.bytes || u.base >= base + bytes) continue;
+    const hipError_t e = hipStreamWaitEvent(st, u.done, 0);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(ctx, SPART_ERR_INVALID, "%s: the workspace is in use by a call on another stream and this call cannot be "
+                  "ordered after it (%s): give every stream its own workspace", who, hipGetErrorString(e));
+    }
+  }
+  return SPART_OK;
+}
+// After a call's last launch: remember (range, stream) and record its completion event.
+int ws_release(spart_ctx* ctx, const char* base, size_t bytes, hipStream_t st, const char* who) {
+  WsUse* slot = nullptr;
+  for (WsUse& u : ctx->ws_uses)
+    if (u.base == base && u.stream == st) slot = &u;
+  if (!slot) {
+    if (ctx->ws_uses.size() < MAX_WS_USES) {
+      WsUse u;
+      if (hipEventCreateWithFlags(&u.done, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(ctx, SPART_ERR_HIP, "%s: cannot create the workspace completion event", who);
+      }
+      ctx->ws_uses.push_back(u);
+      slot = &ctx->ws_uses.back();
+    } else {                                   // reuse the least recently used record (and its event)
+      slot = &ctx->ws_uses[0];
+      for (WsUse& u : ctx->ws_uses)
+        if (u.stamp < slot->stamp) slot = &u;
+    }
+    slot->bytes = 0;
+  }
+  slot->base = base;
+  slot->bytes = bytes > slot->bytes ? bytes : slot->bytes;
+  slot->stream = st;
+  slot->stamp = ++ctx->stamp;
+  const hipError_t e = hipEventRecord(slot->done, st);
+  if (e != hipSuccess) return fail(ctx, SPART_ERR_HIP, "%s: recording the workspace completion event: %s", who, hipGetErrorString(e));
+  return SPART_OK;
+}
 
 // the band kernels address 8 rows of the float64 constant block with a 32-bit byte offset (stage_constants)
 constexpr int64_t SPART_MAX_BATCH = 60000000;
@@ -306,7 +396,7 @@ static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_
     mp.rdry_in = (const T*)opt->rdry_in;
     mat = mp.leaf_refl || mp.leaf_tran || mp.leaf_kchl || mp.soil_refl || mp.soil_dry || mp.rso || mp.rdo || mp.rsd || mp.rdd;
   }
-  if (mat && !chunk_fits_32bit(chunk, ctx->pf, sizeof(T)))
+  if ((mat || mp.rdry_in) && !chunk_fits_32bit(chunk, ctx->pf, sizeof(T)))
     return fail(ctx, SPART_ERR_INVALID, "batch too large for materialised spectra in one call (chunk %d rows x pitch %d)", chunk, ctx->pf);
   const bool full = !(opt && opt->prune_unused_bands);
   if (opt && opt->band_mean && !full)
@@ -338,8 +428,9 @@ static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_
   if (prof) HIP_TRY(ctx, hipEventRecord(ev[1], st));
   // The columns do not depend on the full-band kernel, so the slot pass + sensor kernel run on the context's side stream
   // BESIDE it and fill issue slots it leaves idle; the caller's stream waits for them at the end.
-  const bool fork = bands && ctx->side != nullptr;
-  hipStream_t s2 = fork ? ctx->side : st;
+  SideLane* lane = bands ? lane_for(ctx, st) : nullptr;
+  const bool fork = lane != nullptr;
+  hipStream_t s2 = fork ? lane->side : st;
   auto columns = [&]() -> int {                // slot pass + sensor kernel, on s2
     hipLaunchKernelGGL((k_slots<TG, TO>), dim3((unsigned)((B + 63) / 64)), dim3(256), 0, s2, tabG,
                        cstG, Bp, (const int*)ctx->slot_band, G, (TG*)(want_rsoil ? gs : nullptr),
@@ -358,7 +449,9 @@ static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_
     return SPART_OK;
   };
   auto band_kernels = [&]() -> int {           // the full-band kernel (+ the batch-mean reduction), on the caller's stream
-    const int M = mat ? (mp.rdry_in ? 2 : 1) : 0;
+    // user dry-soil spectra select the reading variant whatever is stored: band sums and band_mean must see the same soil
+    // as the columns (with M = 0 the kernel would mix the GSV soil from params[9..11], which may be NULL with rdry_in)
+    const int M = mp.rdry_in ? 2 : (mat ? 1 : 0);
     const int F = !full ? 0 : (four ? 2 : 1);
 #define SPART_CASE(MM, FF)                                                                                                      \
   if (M == (MM) && F == (FF)) {                                                                                                 \
@@ -389,14 +482,14 @@ static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_
   } else if (!fork) {
     if ((rc = band_kernels()) == SPART_OK) rc = columns();
   } else {                                     // side stream first: its kernels are queued before the 65k workgroups of k_bands
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+    HIP_TRY(ctx, hipEventRecord(lane->fork, st));
+    HIP_TRY(ctx, hipStreamWaitEvent(lane->side, lane->fork, 0));
     rc = columns();
     const int rc2 = band_kernels();
     // whatever happened after the fork, the caller's stream is ordered after the side stream's work again (and a HIP-graph
     // capture in progress gets its join): an error code is returned only after the join has been recorded
-    const hipError_t ej = hipEventRecord(ctx->ev_join, ctx->side);
-    const hipError_t ew = ej == hipSuccess ? hipStreamWaitEvent(st, ctx->ev_join, 0) : ej;
+    const hipError_t ej = hipEventRecord(lane->join, lane->side);
+    const hipError_t ew = ej == hipSuccess ? hipStreamWaitEvent(st, lane->join, 0) : ej;
     if (rc == SPART_OK) rc = rc2;
     if (rc == SPART_OK && ew != hipSuccess) rc = fail(ctx, SPART_ERR_HIP, "spart_run_batch: joining the side stream: %s", hipGetErrorString(ew));
   }
@@ -533,6 +626,21 @@ static int lut_impl(spart_ctx* ctx, int dtype, int64_t B, int nb, const void* lu
   return SPART_OK;
 }
 
+// lock the context, order the call after other streams' use of the workspace, run `body` (the launches), record the
+// workspace's completion event -- also after a failed body: some of its kernels may already be queued
+template <typename F>
+static int guarded(spart_ctx* ctx, const char* who, const void* wsp, size_t bytes, hipStream_t st, F&& body) {
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  int rc = ws_acquire(ctx, (const char*)wsp, bytes, st, who);
+  if (rc) return rc;
+  rc = body();
+  char keep[512];
+  if (rc) std::snprintf(keep, sizeof(keep), "%s", g_err);
+  const int rc2 = ws_release(ctx, (const char*)wsp, bytes, st, who);
+  if (rc) std::snprintf(g_err, sizeof(g_err), "%s", keep);
+  return rc ? rc : rc2;
+}
+
 #ifndef SPART_BUILD_ID
 #define SPART_BUILD_ID "unidentified"      // built outside spart-python_amd/build.py
 #endif
@@ -543,7 +651,7 @@ extern "C" {
 
 const char* spart_build_id(void) { return k_build_id + 15; }
 
-const char* spart_last_error(const spart_ctx* ctx) { return ctx ? ctx->err : g_err; }
+const char* spart_last_error(const spart_ctx*) { return g_err; }
 
 int spart_ctx_nb(const spart_ctx* ctx) { return ctx ? ctx->nb : 0; }
 
@@ -553,6 +661,7 @@ int spart_ctx_set_row_pitch(spart_ctx* ctx, int64_t pitch_full, int64_t pitch_op
   if (pitch_optical == 0) pitch_optical = NWL;
   if (pitch_full < NWLS || pitch_optical < NWL || pitch_full > (1 << 20) || pitch_optical > (1 << 20))
     return fail(ctx, SPART_ERR_INVALID, "row pitch must be >= the row width (%d / %d elements)", NWLS, NWL);
+  std::lock_guard<std::mutex> lock(ctx->mu);
   ctx->pf = (int)pitch_full;
   ctx->po = (int)pitch_optical;
   return SPART_OK;
@@ -573,9 +682,12 @@ int spart_ctx_destroy(spart_ctx* ctx) {
   (void)hipFree(ctx->slot0); (void)hipFree(ctx->slot1); (void)hipFree(ctx->frac); (void)hipFree(ctx->coef);
   (void)hipFree(ctx->econv);
   for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
-  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
-  if (ctx->side) (void)hipStreamDestroy(ctx->side);
+  for (SideLane& l : ctx->lanes) {
+    (void)hipEventDestroy(l.fork);
+    (void)hipEventDestroy(l.join);
+    (void)hipStreamDestroy(l.side);
+  }
+  for (WsUse& u : ctx->ws_uses) (void)hipEventDestroy(u.done);
   delete ctx;
   return SPART_OK;
 }
@@ -624,9 +736,9 @@ int spart_ctx_create(spart_ctx** out, int device, const spart_tables* t) {
   }
   std::vector<float> tabf(tab.begin(), tab.end());
   int rc;
-  if ((rc = upload(ctx, &ctx->tabD, tab)) || (rc = upload(ctx, &ctx->tabF, tabf))) { std::snprintf(g_err, 512, "%s", ctx->err); spart_ctx_destroy(ctx); return rc; }
+  if ((rc = upload(ctx, &ctx->tabD, tab)) || (rc = upload(ctx, &ctx->tabF, tabf))) { spart_ctx_destroy(ctx); return rc; }
   std::vector<double> ea(t->Ea, t->Ea + NWL);
-  if ((rc = upload(ctx, &ctx->Ea, ea))) { std::snprintf(g_err, 512, "%s", ctx->err); spart_ctx_destroy(ctx); return rc; }
+  if ((rc = upload(ctx, &ctx->Ea, ea))) { spart_ctx_destroy(ctx); return rc; }
 
   // --- sensor block
   ctx->nb = t->nb;
@@ -659,7 +771,7 @@ int spart_ctx_create(spart_ctx** out, int device, const spart_tables* t) {
     std::vector<int> sband(nslot > 0 ? nslot : 1, 0);
     for (int ev = 0; ev < NTILE * TILE; ++ev)
       if (need[ev] >= 0) sband[need[ev]] = ev;
-    if ((rc = upload(ctx, &ctx->slot_band, sband))) { std::snprintf(g_err, 512, "%s", ctx->err); spart_ctx_destroy(ctx); return rc; }
+    if ((rc = upload(ctx, &ctx->slot_band, sband))) { spart_ctx_destroy(ctx); return rc; }
     std::vector<double> coef(t->coef, t->coef + (size_t)NCOEF * t->nb);
     std::vector<double> wsrf(t->wl_srf, t->wl_srf + (size_t)t->nsrf * t->nb), psrf(t->p_srf, t->p_srf + (size_t)t->nsrf * t->nb);
     double *d_w = nullptr, *d_p = nullptr;
@@ -667,7 +779,6 @@ int spart_ctx_create(spart_ctx** out, int device, const spart_tables* t) {
     if ((rc = upload(ctx, &ctx->slot0, s0)) || (rc = upload(ctx, &ctx->slot1, s1)) || (rc = upload(ctx, &ctx->frac, fr)) ||
         (rc = upload(ctx, &ctx->coef, coef)) || (rc = upload(ctx, &ctx->econv, ec)) || (rc = upload(ctx, &d_w, wsrf)) ||
         (rc = upload(ctx, &d_p, psrf))) {
-      std::snprintf(g_err, 512, "%s", ctx->err);
       (void)hipFree(d_w); (void)hipFree(d_p);
       spart_ctx_destroy(ctx);
       return rc;
@@ -687,15 +798,9 @@ int spart_ctx_create(spart_ctx** out, int device, const spart_tables* t) {
   }
   {
     const char* e = std::getenv("SPART_SIDE_STREAM");            // "0" keeps every kernel on the caller's stream
-    if (!(e && e[0] == '0')) {
-      if (hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess ||
-          hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
-          hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
-        fail(nullptr, SPART_ERR_HIP, "spart_ctx_create: side stream / events");
-        spart_ctx_destroy(ctx);
-        return SPART_ERR_HIP;
-      }
-    }
+    ctx->side_enabled = !(e && e[0] == '0');
+    ctx->lanes.reserve(MAX_LANES);                                // (pointers into the vector stay valid)
+    ctx->ws_uses.reserve(MAX_WS_USES);
   }
   *out = ctx;
   return SPART_OK;
@@ -704,6 +809,7 @@ int spart_ctx_create(spart_ctx** out, int device, const spart_tables* t) {
 int spart_profile_enable(spart_ctx* ctx, int max_calls) {
   if (!ctx) return fail(nullptr, SPART_ERR_INVALID, "spart_profile_enable: null context");
   DeviceGuard guard(ctx->device);
+  std::lock_guard<std::mutex> lock(ctx->mu);
   ctx->profile = max_calls > 0;
   ctx->ev_used = 0;
   ctx->ev_forked.clear();
@@ -718,6 +824,7 @@ int spart_profile_enable(spart_ctx* ctx, int max_calls) {
 int spart_profile_read_stages(spart_ctx* ctx, double stage_ms[SPART_NSTAGE], int* ncalls) {
   if (!ctx || !stage_ms || !ncalls) return fail(ctx, SPART_ERR_INVALID, "spart_profile_read_stages: null argument");
   DeviceGuard guard(ctx->device);
+  std::lock_guard<std::mutex> lock(ctx->mu);
   static_assert(SPART_NSTAGE + 1 == NEV, "one event more than stages");
   for (int k = 0; k < SPART_NSTAGE; ++k) stage_ms[k] = 0.0;
   int n = 0;
@@ -780,8 +887,10 @@ int spart_prospect_batch(spart_ctx* ctx, int dtype, int64_t B, const double* con
   if (!leaf) return fail(ctx, SPART_ERR_INVALID, "spart_prospect_batch: null leaf");
   for (int i = 0; i < 9; ++i)
     if (!leaf[i]) return fail(ctx, SPART_ERR_INVALID, "spart_prospect_batch: leaf[%d] is null", i);
-  return dtype == SPART_F32 ? prospect_impl<float>(ctx, B, leaf, refl, tran, kchl, wsp, ws, st)
-                            : prospect_impl<double>(ctx, B, leaf, refl, tran, kchl, wsp, ws, st);
+  return guarded(ctx, "spart_prospect_batch", wsp, ws.total, st, [&] {
+    return dtype == SPART_F32 ? prospect_impl<float>(ctx, B, leaf, refl, tran, kchl, wsp, ws, st)
+                              : prospect_impl<double>(ctx, B, leaf, refl, tran, kchl, wsp, ws, st);
+  });
 }
 
 
@@ -791,8 +900,10 @@ int spart_bsm_batch(spart_ctx* ctx, int dtype, int64_t B, const double* const so
   if (!soil) return fail(ctx, SPART_ERR_INVALID, "spart_bsm_batch: null soil");
   for (int i = 0; i < 6; ++i)
     if (!soil[i] && !(rdry_in && i < 3)) return fail(ctx, SPART_ERR_INVALID, "spart_bsm_batch: soil[%d] is null", i);
-  return dtype == SPART_F32 ? bsm_impl<float>(ctx, B, soil, rdry_in, refl, refl_dry, wsp, ws, st)
-                            : bsm_impl<double>(ctx, B, soil, rdry_in, refl, refl_dry, wsp, ws, st);
+  return guarded(ctx, "spart_bsm_batch", wsp, ws.total, st, [&] {
+    return dtype == SPART_F32 ? bsm_impl<float>(ctx, B, soil, rdry_in, refl, refl_dry, wsp, ws, st)
+                              : bsm_impl<double>(ctx, B, soil, rdry_in, refl, refl_dry, wsp, ws, st);
+  });
 }
 
 int spart_lidf_batch(spart_ctx* ctx, int64_t B, const double* LIDFa, const double* LIDFb, double* lidf, void* stream) {
@@ -815,8 +926,10 @@ int spart_sailh_batch(spart_ctx* ctx, int dtype, int64_t B, const void* rho, con
     if (!canopy[i] || !out4[i]) return fail(ctx, SPART_ERR_INVALID, "spart_sailh_batch: canopy/out4[%d] is null", i);
   for (int i = 0; i < 3; ++i)
     if (!angles[i]) return fail(ctx, SPART_ERR_INVALID, "spart_sailh_batch: angles[%d] is null", i);
-  return dtype == SPART_F32 ? sailh_impl<float>(ctx, B, rho, tau, rs, canopy, angles, out4, wsp, ws, st)
-                            : sailh_impl<double>(ctx, B, rho, tau, rs, canopy, angles, out4, wsp, ws, st);
+  return guarded(ctx, "spart_sailh_batch", wsp, ws.total, st, [&] {
+    return dtype == SPART_F32 ? sailh_impl<float>(ctx, B, rho, tau, rs, canopy, angles, out4, wsp, ws, st)
+                              : sailh_impl<double>(ctx, B, rho, tau, rs, canopy, angles, out4, wsp, ws, st);
+  });
 }
 
 int spart_smac_batch(spart_ctx* ctx, int64_t B, const double* const angles[3], const double* const atm[4],
@@ -828,20 +941,22 @@ int spart_smac_batch(spart_ctx* ctx, int64_t B, const double* const angles[3], c
   for (int i = 0; i < 3; ++i) if (!angles[i]) return fail(ctx, SPART_ERR_INVALID, "spart_smac_batch: angles[%d] is null", i);
   for (int i = 0; i < 4; ++i) if (!atm[i]) return fail(ctx, SPART_ERR_INVALID, "spart_smac_batch: atm[%d] is null", i);
   for (int i = 0; i < 9; ++i) if (!out9[i]) return fail(ctx, SPART_ERR_INVALID, "spart_smac_batch: out9[%d] is null", i);
-  ParamPtrs pp;
-  std::memset(&pp, 0, sizeof(pp));
-  for (int i = 0; i < 3; ++i) pp.p[19 + i] = angles[i];
-  for (int i = 0; i < 4; ++i) pp.p[22 + i] = atm[i];
-  double* a = (double*)(wsp + ws.atm_off);
-  int rc = launch_prelude(ctx, false, pp, PRE_ATM, B, ws.Bp, nullptr, nullptr, a, st);
-  if (rc) return rc;
-  Out9 o;
-  for (int i = 0; i < 9; ++i) o.o[i] = out9[i];
-  int64_t n = B * ctx->nb;
-  hipLaunchKernelGGL(k_smac, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)ctx->coef, ctx->nb,
-                     (const double*)a, ws.Bp, B, o);
-  HIP_TRY(ctx, hipGetLastError());
-  return SPART_OK;
+  return guarded(ctx, "spart_smac_batch", wsp, ws.total, st, [&]() -> int {
+    ParamPtrs pp;
+    std::memset(&pp, 0, sizeof(pp));
+    for (int i = 0; i < 3; ++i) pp.p[19 + i] = angles[i];
+    for (int i = 0; i < 4; ++i) pp.p[22 + i] = atm[i];
+    double* a = (double*)(wsp + ws.atm_off);
+    int rc = launch_prelude(ctx, false, pp, PRE_ATM, B, ws.Bp, nullptr, nullptr, a, st);
+    if (rc) return rc;
+    Out9 o;
+    for (int i = 0; i < 9; ++i) o.o[i] = out9[i];
+    int64_t n = B * ctx->nb;
+    hipLaunchKernelGGL(k_smac, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)ctx->coef, ctx->nb,
+                       (const double*)a, ws.Bp, B, o);
+    HIP_TRY(ctx, hipGetLastError());
+    return SPART_OK;
+  });
 }
 
 
@@ -854,18 +969,21 @@ int spart_run_batch(spart_ctx* ctx, int dtype, int64_t B, const double* const pa
   for (int i = 0; i < SPART_NPARAM; ++i)
     if (!params[i] && !(opt && opt->rdry_in && i >= 9 && i <= 11))   // B, lat, lon are unused with user dry spectra
       return fail(ctx, SPART_ERR_INVALID, "spart_run_batch: params[%d] is null", i);
-  if (dtype == SPART_F64 && opt && opt->f32_bands) {
+  if (dtype == SPART_F64 && opt && opt->f32_bands &&
+      (opt->leaf_refl || opt->leaf_tran || opt->leaf_kchl || opt->soil_refl || opt->soil_refl_dry || opt->rso || opt->rdo ||
+       opt->rsd || opt->rdd || opt->band_mean || opt->rdry_in || opt->f32_columns))
     // float64 columns (identical to the float64 mode's) over a float32 full-band pass: nothing the float32 kernel
     // would have to write in float64 may be requested
-    if (opt->leaf_refl || opt->leaf_tran || opt->leaf_kchl || opt->soil_refl || opt->soil_refl_dry || opt->rso || opt->rdo ||
-        opt->rsd || opt->rdd || opt->band_mean || opt->rdry_in || opt->f32_columns)
-      return fail(ctx, SPART_ERR_INVALID, "spart_run_batch: f32_bands goes with the sensor columns (and rsoil / La) only");
-    return run_impl<float, double, double>(ctx, B, params, rho_thermal, tau_thermal, R_TOC, R_TOA, L_TOA, opt, wsp, ws, st);
-  }
-  if (dtype == SPART_F64) return run_impl<double, double, double>(ctx, B, params, rho_thermal, tau_thermal, R_TOC, R_TOA, L_TOA, opt, wsp, ws, st);
-  return (opt && opt->f32_columns)
-             ? run_impl<float, float, float>(ctx, B, params, rho_thermal, tau_thermal, R_TOC, R_TOA, L_TOA, opt, wsp, ws, st)
-             : run_impl<float, double, float>(ctx, B, params, rho_thermal, tau_thermal, R_TOC, R_TOA, L_TOA, opt, wsp, ws, st);
+    return fail(ctx, SPART_ERR_INVALID, "spart_run_batch: f32_bands goes with the sensor columns (and rsoil / La) only");
+  return guarded(ctx, "spart_run_batch", wsp, ws.total, st, [&] {
+    if (dtype == SPART_F64 && opt && opt->f32_bands)
+      return run_impl<float, double, double>(ctx, B, params, rho_thermal, tau_thermal, R_TOC, R_TOA, L_TOA, opt, wsp, ws, st);
+    if (dtype == SPART_F64)
+      return run_impl<double, double, double>(ctx, B, params, rho_thermal, tau_thermal, R_TOC, R_TOA, L_TOA, opt, wsp, ws, st);
+    return (opt && opt->f32_columns)
+               ? run_impl<float, float, float>(ctx, B, params, rho_thermal, tau_thermal, R_TOC, R_TOA, L_TOA, opt, wsp, ws, st)
+               : run_impl<float, double, float>(ctx, B, params, rho_thermal, tau_thermal, R_TOC, R_TOA, L_TOA, opt, wsp, ws, st);
+  });
 }
 
 size_t spart_lut_workspace_bytes(int dtype, int64_t B, int nb, int64_t M) {
@@ -888,8 +1006,10 @@ int spart_lut_nearest(spart_ctx* ctx, int dtype, int64_t B, int nb, const void* 
     return fail(ctx, SPART_ERR_WORKSPACE, "spart_lut_nearest: workspace of %zu bytes needed, %zu given", need, workspace_bytes);
   DeviceGuard guard(ctx->device);
   hipStream_t st = (hipStream_t)stream;
-  return dtype == SPART_F32 ? lut_impl<float>(ctx, dtype, B, nb, lut, M, obs, weights, best_idx, best_cost, (char*)workspace, st)
-                            : lut_impl<double>(ctx, dtype, B, nb, lut, M, obs, weights, best_idx, best_cost, (char*)workspace, st);
+  return guarded(ctx, "spart_lut_nearest", workspace, need, st, [&] {
+    return dtype == SPART_F32 ? lut_impl<float>(ctx, dtype, B, nb, lut, M, obs, weights, best_idx, best_cost, (char*)workspace, st)
+                              : lut_impl<double>(ctx, dtype, B, nb, lut, M, obs, weights, best_idx, best_cost, (char*)workspace, st);
+  });
 }
 
 int spart_lut_stats(spart_ctx* ctx, int dtype, int64_t B, int nb, int64_t M, const void* workspace, int64_t* n_brute_force,

@@ -68,7 +68,7 @@ class Engine:
         rc = self.lib.spart_ctx_create(ctypes.byref(ctx), device, ctypes.byref(t))
         _lib.check(self.lib, None, rc)
         self.ctx = ctx
-        self._ws_buf = None
+        self._ws_buf = {}                         # scratch per torch stream (see _workspace)
         self.calls = collections.Counter()        # C-ABI compute calls issued through this engine, by entry point
         self.row_pitch = {_lib.NWLS: _lib.NWLS, _lib.NWL: _lib.NWL}
         if row_pitch is not None:
@@ -89,15 +89,20 @@ class Engine:
         return ctypes.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
 
     def _workspace(self, dt, B):
+        """The scratch buffer of the CURRENT torch stream: calls issued on different streams (from one or several host
+        threads) run concurrently on the GPU, so each stream gets its own.  (The library would also accept one buffer for
+        all of them -- it orders a call after the previous user of its workspace -- but that serialises the streams.)"""
         n = int(self.lib.spart_workspace_bytes(self.ctx, dt, B))
-        if self._ws_buf is None or self._ws_buf.numel() < n:
-            self._ws_buf = self.torch.empty(max(n, 256), dtype=self.torch.uint8, device=self.device)
-        return ctypes.c_void_p(self._ws_buf.data_ptr()), ctypes.c_size_t(self._ws_buf.numel())
+        key = self.torch.cuda.current_stream(self.device).cuda_stream
+        buf = self._ws_buf.get(key)
+        if buf is None or buf.numel() < n:
+            buf = self._ws_buf[key] = self.torch.empty(max(n, 256), dtype=self.torch.uint8, device=self.device)
+        return ctypes.c_void_p(buf.data_ptr()), ctypes.c_size_t(buf.numel())
 
     def release_workspace(self):
-        """Drop the scratch buffer the engine keeps between calls (it grows to the largest batch seen: ~1.7 KB per
-        sample); the next call allocates what it needs."""
-        self._ws_buf = None
+        """Drop the scratch buffers the engine keeps between calls (one per stream used; each grows to the largest batch
+        seen: ~1.7 KB per sample); the next call allocates what it needs."""
+        self._ws_buf = {}
 
     def to_f64(self, x, B=None):
         """scalar / sequence / numpy / tensor -> contiguous float64 device tensor of length B."""

@@ -924,6 +924,92 @@ def test_user_dry_soil_spectra_full_chain(golden, dtype, torch_mod):
     assert rel_err(out["soil_refl_dry"].cpu().numpy(), g["spectra"], 1e-3) < 1e-6
 
 
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_band_mean_with_user_dry_soil_and_no_spectra(dtype, torch_mod):
+    """band_mean requested together with user dry-soil spectra but WITHOUT any materialised spectrum: the
+    full-band kernel must read the user's spectra (its MAT = 2 variant), not mix a soil from the absent GSV columns --
+    band_mean equals the batch mean of the canopy rows of a call that does materialise them, bit for bit, and differs
+    from the GSV-soil means."""
+    from spart_amd import get_engine, workloads
+    eng = get_engine("Sentinel2A-MSI", 0)
+    B = 700
+    P = workloads.lhs_params(B, "full", seed=21)
+    rng = np.random.default_rng(3)
+    wl = np.arange(2001)
+    rdry = 0.1 + 0.3 * rng.uniform(0, 1, (B, 1)) * (1 + 0.3 * np.sin(wl[None, :] / 150.0 + rng.uniform(0, 6, (B, 1))))
+    cols = [P[:, j] for j in range(27)]
+    cols[9] = cols[10] = cols[11] = None               # B, lat, lon: legally absent with rdry_in
+    only = eng.run(cols, dtype, rdry=rdry, materialize=("band_mean",))
+    bm_only = only["band_mean"].clone()
+    both = eng.run(cols, dtype, rdry=rdry, materialize=("band_mean", "rso", "rdo", "rsd", "rdd"))
+    assert torch_mod.equal(bm_only, both["band_mean"])
+    for q, k in enumerate(("rso", "rdo", "rsd", "rdd")):
+        m = both[k].double().mean(dim=0)
+        assert float(((bm_only[q].double() - m).abs() / m.abs().clamp_min(1e-3)).max()) < (2e-5 if dtype == "float32" else 1e-10), k
+    for k in ("R_TOC", "R_TOA", "L_TOA"):
+        assert torch_mod.equal(only[k], both[k])
+    gsv = eng.run(torch_mod.as_tensor(P.T.copy(), device="cuda:0"), dtype, materialize=("band_mean",))["band_mean"]
+    assert float((gsv - bm_only).abs().max()) > 1e-3   # (a different soil gives different means: the check above is not vacuous)
+
+
+def test_one_engine_from_two_threads_and_streams(torch_mod):
+    """SURVEY.md section 8(b) "Threading": a context is thread-safe.  Two host threads, each on its own torch stream,
+    issue 20 interleaved run() calls each (different batches, dtypes and modes, full evaluation = side-stream fork / join)
+    on ONE engine; every result must be bit-identical to the serial evaluation of the same call.  Then the case the
+    engine avoids on purpose: two streams handing the library the SAME workspace -- the library orders the second call
+    after the first (include/spart_hip.h), so the results are still the serial ones."""
+    import threading
+    from spart_amd import get_engine, workloads
+    torch = torch_mod
+    eng = get_engine("Sentinel2A-MSI", 0)
+    jobs = []
+    for i in range(40):
+        B = 2000 + 997 * (i % 7)
+        P = torch.as_tensor(workloads.lhs_params(B, "full", seed=100 + i).T.copy(), device="cuda:0")
+        kw = [dict(dtype="float32"), dict(dtype="float64"), dict(dtype="float32", materialize=("rso", "rsoil")),
+              dict(dtype="float32", prune=True)][i % 4]
+        jobs.append((P, kw))
+    serial = []
+    for P, kw in jobs:
+        serial.append({k: v.clone() for k, v in eng.run(P, **kw).items()})
+    torch.cuda.synchronize()
+    results, errors = [None] * len(jobs), []
+
+    def worker(tid):
+        try:
+            st = torch.cuda.Stream("cuda:0")
+            with torch.cuda.stream(st):
+                for i in range(tid, len(jobs), 2):
+                    P, kw = jobs[i]
+                    results[i] = {k: v.clone() for k, v in eng.run(P, **kw).items()}
+            st.synchronize()
+        except Exception as e:      # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i, (ref, got) in enumerate(zip(serial, results)):
+        for k in ref:
+            assert torch.equal(ref[k], got[k]), (i, k)
+    # one workspace shared by two streams: ordered by the library, results unchanged
+    n = max(int(eng.lib.spart_workspace_bytes(eng.ctx, 1, P.shape[1])) for P, _ in jobs)
+    ws = torch.empty(n, dtype=torch.uint8, device="cuda:0")
+    sa, sb = torch.cuda.Stream("cuda:0"), torch.cuda.Stream("cuda:0")
+    shared = [None] * 12
+    for i in range(12):
+        with torch.cuda.stream(sa if i % 2 == 0 else sb):
+            P, kw = jobs[i]
+            shared[i] = eng.run(P, _workspace=ws, **kw)
+    torch.cuda.synchronize()
+    for i in range(12):
+        for k in serial[i]:
+            assert torch.equal(serial[i][k], shared[i][k]), ("shared workspace", i, k)
+
+
 def test_row_pitch_dense_and_padded_agree(torch_mod):
     """spart_ctx_set_row_pitch: the padded default (rows on the 128 B line grid) and the dense layout give
     bit-identical spectra through every entry point that reads or writes (B,2162) / (B,2001) arrays, including
