@@ -516,10 +516,50 @@ def main():
     dt = time.perf_counter() - t0
     stage, ncalls = eng.profile_read_stages()
     eng.profile(0)
+    own_dt = dt
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # Self-diagnosis of a multi-rank run (nobody watches the driver's 8-GPU job): AFTER the timed region every rank times
+    # its own compute-only steps and one gather on its own, and rank 0 prints what every rank saw.  A slow rank, a rank-0
+    # gather skew or a wrong rank count then shows in the line itself.
+    diag = None
+    if world > 1:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            if B:
+                eng.run(P, args.dtype, out=dict(outs[0]))
+        torch.cuda.synchronize()
+        compute_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            dist.gather(res[0], gather_lists[0] if rank == 0 else None, dst=0)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - t1) / 3 * 1e3
+        ones = torch.ones(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(ones)
+        info = {"rank": rank, "device": dev_index, "rows": B, "step_ms": own_dt / args.steps * 1e3, "compute_ms": compute_ms,
+                "band_kernel_ms": stage.get("bands", 0.0) / max(ncalls, 1), "gather_ms": gather_ms}
+        infos = [None] * world
+        dist.all_gather_object(infos, info)
+        infos = sorted(infos, key=lambda r: r["rank"])
+        slow = max(r["compute_ms"] for r in infos)
+        diag = {"ranks_seen": int(round(float(ones.item()))), "ranks": [r["rank"] for r in infos], "devices": [r["device"] for r in infos],
+                "rows_per_rank": [r["rows"] for r in infos],
+                "per_rank_ms": [r["step_ms"] for r in infos],
+                "per_rank_compute_ms": [r["compute_ms"] for r in infos],
+                "per_rank_band_kernel_ms": [r["band_kernel_ms"] for r in infos],
+                "gather_ms": infos[0]["gather_ms"], "per_rank_gather_ms": [r["gather_ms"] for r in infos],
+                "predicted_value": Bg / (slow * 1e-3) if slow > 0 else None,
+                "gather_exposed_ms": dt / args.steps * 1e3 - slow,
+                "note": ("measured after the timed region, no collective added inside it: per_rank_ms = each rank's own clock over "
+                         "the timed steps; per_rank_compute_ms = the same steps without the gather; gather_ms = one (3, B/N, nb) "
+                         "gather to rank 0 on its own (rank 0's clock); predicted_value = global batch / slowest rank's compute "
+                         "= the rate with the gather fully hidden; gather_exposed_ms = ms_per_step - slowest compute")}
 
     if rank == 0:
         ok = all(bool(torch.isfinite(r).all().item()) for r in res)
@@ -557,6 +597,8 @@ def main():
             "roofline": roofline(args.dtype, B, nb, stage_ms, dt / args.steps * 1e3, band_kernel),
         }
         line["cpu_baseline"] = cpu
+        if diag is not None:
+            line["multi_rank"] = diag
         if world == 1 and "columns_beside_bands" in line["roofline"]["stage_ms"]:
             ser = serial_stages(torch, args.sensor, dev_index, P, args.dtype)
             line["roofline"]["stage_ms_serial"] = ser

@@ -452,9 +452,17 @@ __global__ __launch_bounds__(TILE) void k_prospect(const T* __restrict__ tab, co
   if (o_kchl) o_kchl += s0 * po;
   for_samples_staged<T, sizeof(T) == 4>(cst, Bp, s0, s1, [&](int64_t, auto c) {
     T refl, tran, absb, K;
+#if defined(SPART_X_STOREONLY)
+    refl = c[C_CAB] * tb.kab; tran = c[C_CW] * tb.kw; K = c[C_CDM] + tb.kdm; absb = 0;
+#else
     leaf_band<T>(tb, c[C_CAB], c[C_CCA], c[C_CDM], c[C_CW], c[C_CS], c[C_CANT], c[C_CBC], c[C_PROT], c[C_NM1], refl,
                  tran, absb, K);
+#endif
+#if defined(SPART_X_NOSTORE)
+    if (active && refl + tran + K == T(-12345.678)) {
+#else
     if (active) {
+#endif
       if (o_refl) store_row<NT>(o_refl, off, refl);
       if (o_tran) store_row<NT>(o_tran, off, tran);
       if (o_kchl) store_row<NT>(o_kchl, off, (K > T(0)) ? divx(c[C_CAB] * tb.kab, K) : T(0));

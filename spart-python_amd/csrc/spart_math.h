@@ -278,10 +278,11 @@ template <> struct Mx<double> {
 #endif
   // square root: v_rsq_f64 (4.6e-8 relative) refined by ONE Newton step, sqrt x = g (1 + e/2 + O(e^2)), g = x y0,
   // e = 1 - g y0: relative error 3 e^2 / 8 < 1e-15 in 5 instructions (the library's sequence: ~14).  The argument of the
-  // rsq is kept away from 0 (x = 0 -> 0 * rsq(tiny) = 0 instead of 0 * inf); a NaN x stays NaN through g.
+  // rsq is kept away from 0 by ADDING 1e-300 (x = 0 -> 0 * rsq(1e-300) = 0 instead of 0 * inf; x + 1e-300 == x for every
+  // normal x): a negative x gives NaN like np.sqrt (a max() here returned finite garbage), a NaN x stays NaN.
   static SPART_HD double sqrt(double x) {
 #if defined(__HIP_DEVICE_COMPILE__) && defined(SPART_FAST_MATH)
-    const double y0 = __builtin_amdgcn_rsq(__builtin_fmax(x, 1e-300));
+    const double y0 = __builtin_amdgcn_rsq(x + 1e-300);
     const double g = x * y0;
     const double e = __builtin_fma(-g, y0, 1.0);
     return __builtin_fma(g * 0.5, e, g);
@@ -318,7 +319,7 @@ template <> struct Mx<double> {
     return ::log1p(x);
 #endif
   }
-  // 1 - e^-z, z >= 0: Taylor below 0.02 (z^9/9! < 2e-21), direct above (cancellation <= 1e-16/0.02 relative)
+  // 1 - e^-z: Taylor for |z| below 0.02 (z^9/9! < 2e-21), direct otherwise (cancellation <= 1e-16/0.02 relative)
   static SPART_HD double omen_taylor(double z) {
     double p = -1.0 / 40320.0;
     p = p * z + 1.0 / 5040.0;
@@ -332,7 +333,7 @@ template <> struct Mx<double> {
   }
   static SPART_HD double one_minus_exp_neg(double z) {
 #if defined(SPART_FAST_MATH)
-    if (z < 0.02) return omen_taylor(z);
+    if (::fabs(z) < 0.02) return omen_taylor(z);   // (|z|: a negative z -- N < 1, LAI < 0 -- must not take the series)
     return 1.0 - exp(-z);
 #else
     return -::expm1(-z);
@@ -341,14 +342,14 @@ template <> struct Mx<double> {
   // (the prelude's form: no table, see exp_poly)
   static SPART_HD double one_minus_exp_neg_poly(double z) {
 #if defined(SPART_FAST_MATH)
-    return (z < 0.02) ? omen_taylor(z) : 1.0 - exp_poly(-z);
+    return (::fabs(z) < 0.02) ? omen_taylor(z) : 1.0 - exp_poly(-z);
 #else
     return -::expm1(-z);
 #endif
   }
   static SPART_HD double one_minus_exp_neg(double z, double ez) {
 #if defined(SPART_FAST_MATH)
-    return (z < 0.02) ? omen_taylor(z) : 1.0 - ez;
+    return (::fabs(z) < 0.02) ? omen_taylor(z) : 1.0 - ez;
 #else
     (void)ez;
     return -::expm1(-z);

@@ -504,9 +504,12 @@ class SPART:
         bands = self.sensorinfo["band_id_smac"]
         # attributes documented at SPART.py:66-81
         self.R_TOC, self.R_TOA, self.L_TOA, self._La = out["R_TOC"], out["R_TOA"], out["L_TOA"], out["La"]
-        # what the lazy attributes are evaluated from: the parameters of THIS run (the objects may be modified afterwards)
-        self.__dict__["_last"] = dict(eng=eng, cols=cols, th=th, rdry=rdry, scalar=scalar,
-                                      angles=self.angles.columns(), atm=self.atm.columns())
+        # what the lazy attributes are evaluated from: COPIES of the parameters and the dtype of THIS run (the reference sets the
+        # attributes eagerly in run(): mutating an input array in place or changing sp.dtype afterwards must not change them)
+        snap = lambda c: None if c is None else (np.array(c, copy=True) if isinstance(c, np.ndarray) else (c.clone() if hasattr(c, "clone") else c))  # noqa: E731
+        self.__dict__["_last"] = dict(eng=eng, dtype=self.dtype, cols=[snap(c) for c in cols], th=tuple(snap(t) for t in th),
+                                      rdry=snap(rdry), scalar=scalar,
+                                      angles=[snap(c) for c in self.angles.columns()], atm=[snap(c) for c in self.atm.columns()])
         for k in self._LAZY:
             self.__dict__.pop(k, None)
         if materialize:
@@ -537,7 +540,7 @@ class SPART:
                 sm = eng.smac(last["angles"], last["atm"])
                 self.__dict__["atmopt"] = AtmosphericOptics(*[_np(sm[f]) for f in _engine.SMAC_FIELDS])
             else:
-                res = eng.run(last["cols"], self.dtype, rho_thermal=last["th"][0], tau_thermal=last["th"][1],
+                res = eng.run(last["cols"], last["dtype"], rho_thermal=last["th"][0], tau_thermal=last["th"][1],
                               materialize=_SPECTRA, rdry=last["rdry"])
                 self._set_spectra({k: _np(res[k]) for k in _SPECTRA}, last["scalar"])
             return self.__dict__[name]

@@ -135,3 +135,12 @@ def test_bench_under_the_drivers_multi_rank_invocation():
     assert b["config"]["columns_checksum"] == a["config"]["columns_checksum"]       # the gathered columns ARE the single-rank columns
     # (gloo moves the result blocks through host memory and both ranks share one GPU: the rate is a sanity bound only)
     assert 0.05 * a["value"] < b["value"] < 1.5 * a["value"], (a["value"], b["value"])
+    # the self-diagnosis of a multi-rank run (nobody can watch the driver's 8-GPU job): every rank reported
+    m = b["multi_rank"]
+    assert "multi_rank" not in a
+    assert m["ranks_seen"] == 2 and m["ranks"] == [0, 1] and m["rows_per_rank"] == [100000, 100000]
+    for k in ("per_rank_ms", "per_rank_compute_ms", "per_rank_band_kernel_ms", "per_rank_gather_ms"):
+        assert len(m[k]) == 2 and all(np.isfinite(v) and v > 0 for v in m[k]), (k, m[k])
+    assert m["gather_ms"] > 0 and np.isfinite(m["predicted_value"]) and m["predicted_value"] > 0
+    assert max(m["per_rank_ms"]) <= b["ms_per_step"] * 1.001          # ms_per_step IS the maximum over the ranks' own clocks
+    assert abs(m["gather_exposed_ms"] - (b["ms_per_step"] - max(m["per_rank_compute_ms"]))) < 1e-9
