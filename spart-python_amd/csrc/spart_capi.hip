@@ -558,8 +558,10 @@ static LutLayout lut_layout(int dtype, int64_t B, int nb, int64_t M) {
   L.total = o;
   return L;
 }
-// Delta = coef * (Nmax + Y): spart_lut.h derives 2 (3 nb + 2 K + 13) u; + 3 and 1 % for the second-order terms
-static double lut_delta_coef(int nb, int kfma, double u) { return 2.0 * (3.0 * nb + 2.0 * kfma + 16.0) * 1.01 * u; }
+// Delta = coef_ef * [(N_a + Y) + (N_b + Y)]: spart_lut.h derives (3 nb + 2 K + 13) u; + 3 and 1 % for the second-order terms.
+// coef_e: the filter's own error E = (nb + 2 K + 7) u (N + Y), with the same slack
+static double lut_coef_ef(int nb, int kfma, double u) { return (3.0 * nb + 2.0 * kfma + 16.0) * 1.01 * u; }
+static double lut_coef_e(int nb, int kfma, double u) { return (nb + 2.0 * kfma + 10.0) * 1.01 * u; }
 
 template <typename T>
 static int lut_impl(spart_ctx* ctx, int dtype, int64_t B, int nb, const void* lut_, int64_t M, const void* obs_,
@@ -601,10 +603,11 @@ static int lut_impl(spart_ctx* ctx, int dtype, int64_t B, int nb, const void* lu
 #undef SPART_LUT_KS
   }
   HIP_TRY(ctx, hipGetLastError());
-  const T coef = (T)lut_delta_coef(nb, L.kfma, (double)LutNum<T>::u);
+  const T coef_ef = (T)lut_coef_ef(nb, L.kfma, (double)LutNum<T>::u), coef_e = (T)lut_coef_e(nb, L.kfma, (double)LutNum<T>::u);
   const dim3 gobs((unsigned)((M + 3) / 4));                // one wave per observation
   hipLaunchKernelGGL((k_lut_reduce_exact<T, (sizeof(T) == 4 ? 32 : 16)>), gobs, dim3(256), 0, st, (const T*)pc, (const T*)ps,
-                     (const int*)pt, lut, obs, w, (const T*)centre, nb, B, M, L.npart, coef, ctl, flags, best_idx, (T*)best_cost);
+                     (const int*)pt, (const T*)tiles, L.ks, lut, obs, w, (const T*)centre, nb, B, M, L.npart, coef_e, coef_ef, ctl,
+                     flags, best_idx, (T*)best_cost);
   HIP_TRY(ctx, hipGetLastError());
   // the flagged observations (normally a handful, possibly all of them for degenerate data): the grid is fixed, the
   // kernels read the count on the device, so the call stays asynchronous and graph-capturable

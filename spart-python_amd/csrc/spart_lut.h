@@ -33,10 +33,19 @@
 //   (iv)  a chain of K fmas (any order):                   <= K u (|n_b| + 2 sum |w x' y'|) <= 2 K u (N_b + Y)
 //   =>    | a~(b) + Y - c(b) | <= E = (nb + 2 K + 7) u (N_b + Y)
 //   (v)   direct evaluation:  | c_T(b) - c(b) | <= F = (nb + 3) u sum |w| d^2 <= (2 nb + 6) u (N_b + Y)
-// If b is the argmin of c_T and a the row with a~(a) = g:  a~(b) + Y <= c(b) + E <= c_T(b) + E + F <= c_T(a) + E + F
-// <= c(a) + E + 2 F <= g + Y + 2 E + 2 F, i.e. a~(b) <= g + Delta with Delta = 2 (3 nb + 2 K + 13) u (Nmax + Y).  The code
-// uses 2 (3 nb + 2 K + 16) * 1.01 (second-order terms, the rounding of g + Delta and of Y itself) plus 2^-100 / 1e-290 for
-// products that underflow.
+// If b is the argmin of c_T and a the row with a~(a) = g:  a~(b) + Y <= c(b) + E_b <= c_T(b) + E_b + F_b <= c_T(a) + E_b + F_b
+// <= c(a) + F_a + E_b + F_b <= g + Y + (E_a + F_a) + (E_b + F_b), i.e. a~(b) <= g + Delta with
+//     Delta = (3 nb + 2 K + 13) u [(N_a + Y) + (N_b + Y)].
+// N_a and N_b are not known to the reduce kernel, but bounded:
+//   * always:  N_a, N_b <= Nmax  (the prep kernel's maximum over all finite rows);
+//   * with non-negative weights (c is then a squared distance in the |w|-weighted norm), per observation:
+//       N_a <= Na = max of n over the rows of the tile that produced g (read back from the operand image);
+//       c(a) <= max(0, g + Y) + E_a =: cub;  c(b) <= c(a) (1 + 3 (nb + 3) u);  sqrt(N_b) <= sqrt(Y) + sqrt(c'(b)) with
+//       c'(b) = sum w (x'_b - y')^2 <= c(b) + 4 u (Nmax + Y)   =>   N_b <= Nstar = (sqrt(Y) + sqrt(cub + 4 u (Nmax + Y)))^2.
+//     For a LUT of spectra and an observation that resembles some of them Na and Nstar are ~Y, an order of magnitude below
+//     Nmax: fewer candidate tiles, and far fewer observations for which the scan's top-1 + runner-up per slice is not enough.
+// The code uses (3 nb + 2 K + 16) * 1.01 (second-order terms, the rounding of g + Delta and of Y itself, the square roots)
+// plus 2^-100 / 1e-290 for products that underflow.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -315,12 +324,13 @@ __device__ __forceinline__ bool lut_better(T oc, int64_t oi, T bc, int64_t bi) {
 
 template <typename T, int ROWS>
 __global__ __launch_bounds__(256) void k_lut_reduce_exact(const T* __restrict__ part_cost, const T* __restrict__ part_sec,
-                                                          const int* __restrict__ part_tile, const T* __restrict__ lut,
-                                                          const T* __restrict__ obs, const T* __restrict__ w,
-                                                          const T* __restrict__ centre, int nb, int64_t B, int64_t M, int npart,
-                                                          T coef, unsigned long long* __restrict__ ctl, int* __restrict__ flag_list,
+                                                          const int* __restrict__ part_tile, const T* __restrict__ tiles, int ks,
+                                                          const T* __restrict__ lut, const T* __restrict__ obs,
+                                                          const T* __restrict__ w, const T* __restrict__ centre, int nb, int64_t B,
+                                                          int64_t M, int npart, T coef_e, T coef_ef,
+                                                          unsigned long long* __restrict__ ctl, int* __restrict__ flag_list,
                                                           int64_t* __restrict__ best_idx, T* __restrict__ best_cost) {
-  constexpr int NG = 64 / ROWS;                        // candidate tiles evaluated side by side
+  constexpr int NG = 64 / ROWS;                        // candidate tiles evaluated side by side (= k columns per operand register)
   __shared__ T ysm[4][32], wsm[32];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t mraw = (int64_t)blockIdx.x * 4 + wv;
@@ -340,25 +350,57 @@ __global__ __launch_bounds__(256) void k_lut_reduce_exact(const T* __restrict__ 
     return;
   }
   T ya = T(0);
+  bool wneg = false;
   if (lane < nb) {
     const T yc = yv - centre[lane];
     const T wj = w ? w[lane] : T(1);
-    ya = (wj < T(0) ? -wj : wj) * yc * yc;
+    wneg = wj < T(0);
+    ya = (wneg ? -wj : wj) * yc * yc;
   }
+  wneg = __any(wneg) != 0;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) ya += __shfl_xor(ya, off, 64);
   T g = (T)INFINITY;
+  int ta = -1;
   for (int p = lane; p < npart; p += 64) {
     const T c = part_cost[(int64_t)p * M + m];
-    if (part_tile[(int64_t)p * M + m] >= 0 && c < g) g = c;
+    const int t = part_tile[(int64_t)p * M + m];
+    if (t >= 0 && c < g) {
+      g = c;
+      ta = t;
+    }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     const T o = __shfl_xor(g, off, 64);
-    g = o < g ? o : g;
+    const int ot = __shfl_xor(ta, off, 64);
+    if (o < g || (o == g && ot > ta)) {                // (any tile that attains g will do; the tie rule only makes all lanes agree)
+      g = o;
+      ta = ot;
+    }
   }
   const T nmax = LutNum<T>::from_bits(ctl[0]);
-  const T thr = g + (coef * (nmax + ya) + LutNum<T>::tiny);
+  T na = nmax, nstar = nmax;
+  if (!wneg && ta >= 0) {
+    // N_a <= the largest n among the rows of tile ta (n = sum w x'^2 = N for w >= 0; padding / non-finite rows hold +inf)
+    T v = T(0);
+    if (lane < ROWS) {
+      const T n = tiles[((int64_t)ta * ks + nb / NG) * 64 + (nb % NG) * ROWS + lane];
+      v = LutNum<T>::finite(n) ? n : T(0);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const T o = __shfl_xor(v, off, 64);
+      v = o > v ? o : v;
+    }
+    const T gy = g + ya;
+    const T cub = ((gy > T(0) ? gy : T(0)) + T(2) * coef_e * (v + ya) + T(4) * LutNum<T>::u * (nmax + ya)) * T(1.001);
+    const T r = (T)__builtin_sqrt((double)ya) + (T)__builtin_sqrt((double)cub);
+    const T ns = r * r * T(1.001);
+    if (v < na) na = v;
+    if (ns < nstar) nstar = ns;                        // (never above the global bound; NaN / inf leave it in place)
+  }
+  const T thr = g + (coef_ef * ((na + ya) + (nstar + ya)) + LutNum<T>::tiny);
   // no finite filter value (e.g. an all-NaN LUT) or no finite threshold (overflow): let the brute force decide
   bool over = !(g < (T)INFINITY) || !LutNum<T>::finite(thr);
   T bc = (T)INFINITY;
