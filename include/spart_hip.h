@@ -109,10 +109,17 @@ typedef struct spart_materialize {
                                   Materialised spectra, band_mean and rdry_in cannot be combined with it (SPART_ERR_INVALID). */
   int32_t fast_prelude;        /* 0 (default): the reference's own LIDF fixed-point iteration with its |dx| <= 1e-8 stopping rule
                                   (sailh.py:378-382) and 10-point hot-spot panels -- the columns agree with the reference to
-                                  ~1e-11.  1: the root of the same equation by Newton (the reference stops up to ~5e-8 short
-                                  of it) and 8-point panels: R_TOC / R_TOA / L_TOA move by <= 1e-7 relative (inside the
-                                  1e-6 / 1e-4 contract; measured per run in bench.py configs.fast_prelude), the per-sample
-                                  prelude kernel takes half the time (0.93 -> 0.45 ms per 1M spectra) */
+                                  ~1e-11.  1: the ROOT of the same equation by Newton (the reference stops up to ~5e-8 short
+                                  of it) and 8-point panels; the per-sample prelude kernel takes half the time (0.93 -> 0.45 ms
+                                  per 1M spectra).  It is a different function at the 1e-8 level.  Measured over all 2 x 13M
+                                  float64 column entries of BASELINE configs 4 and 5 (1M rows each; bench.py
+                                  configs.fast_prelude.float64_columns_vs_default and test_fast_prelude_at_size repeat the
+                                  measurement): on SURVEY 8(d)'s metric |d| / max(|ref|, 1e-6) the median is 2.5e-10, 99.999 % of
+                                  the entries of R_TOC / R_TOA / L_TOA are within 1.5e-7, and 15 + 27 of the 2 x 13M R_TOC
+                                  entries exceed 1e-6 (maximum 1.7e-5) -- every one of them an entry whose own magnitude is
+                                  below 1e-3 (strongly absorbing bands, |d| < 1e-9).  So: inside the float32 contract (1e-4)
+                                  everywhere, inside the float64 contract (1e-6) wherever the value is at least 1e-3.
+                                  Implied by f32_columns */
 } spart_materialize;
 
 int spart_ctx_create(spart_ctx **out, int device, const spart_tables *tables);
