@@ -24,7 +24,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "spart-python_amd"))
 
-PROFILE_TAGS = ("r3", "r2")   # profiles/<tag>_counters_<what>.json: the committed rocprofv3 PMC passes (tools/ingest_profiles.py), newest first
+PROFILE_TAGS = ("r4", "r3", "r2")   # profiles/<tag>_counters_<what>.json: the committed rocprofv3 PMC passes (tools/ingest_profiles.py), newest first
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_TFLOPS = {"float32": 157.3, "float64": 78.6}   # MI355X_MICROARCH.md: peak FP32 / FP64 vector
 ISSUE_CYCLES = {"float32": 2.0, "float64": 4.0}          # cycles per wave64 VALU instruction on a SIMD-32 (fp64: half rate)

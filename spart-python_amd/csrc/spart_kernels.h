@@ -230,12 +230,29 @@ void k_bands(const T* __restrict__ tab, const T* __restrict__ cst, int64_t Bp, i
   // (profiles/r1_ubench_valu_issue.txt), and ~60 ops per band use these constants -- the same kernel with
   // scalar loads (s_load_dwordx8 -> SGPR operands) is 6 % slower.
   constexpr int SUB = 32;
+#ifndef SPART_HOIST_FILM
+#define SPART_HOIST_FILM (sizeof(T) == 8)
+#endif
+  constexpr bool HOIST_FILM = SPART_HOIST_FILM;
   __shared__ __attribute__((aligned(16))) T lds_c[SUB * NCONST];
   for (int64_t sb = s0; sb < s1; sb += SUB) {
   const int nsub = (int)((s1 - sb < SUB) ? (s1 - sb) : SUB);
   __syncthreads();                                     // the previous sub-chunk has been consumed by every wave
   stage_constants<T>(lds_c, cst + sb, Bp, nsub);
   __syncthreads();
+  // The water film's single-layer transmittance exp2(-film2l kw) depends on the band and the film thickness only.  LUTs
+  // are usually generated with ONE film thickness (BASELINE configs 3-5 fix it), so when the samples staged here all share
+  // it the lane evaluates it once per 32 samples instead of once per sample (same value: the same function of the same
+  // arguments); any other input takes the per-sample path below.
+  bool film_same = false;
+  T tw1s = T(0);
+  if (HOIST_FILM) {
+    const int l = threadIdx.x & 63;
+    const T f0 = lds_c[C_FILM2L];
+    const T fl = lds_c[(l < nsub ? l : 0) * NCONST + C_FILM2L];
+    film_same = __all(fl == f0) != 0;                  // (wave-uniform; a NaN thickness compares unequal: per-sample path)
+    if (film_same) tw1s = soil_tw1<T>(tb, f0);
+  }
   // the nine leaf constants are read one sample ahead (they are the first thing an iteration needs: without the
   // prefetch every iteration starts by waiting for its own LDS reads).  Not in the materialising variants: there the
   // nine registers cost a wave of occupancy (109 VGPRs).
@@ -278,7 +295,12 @@ void k_bands(const T* __restrict__ tab, const T* __restrict__ cst, int64_t Bp, i
     T rdry = (MAT == 2) ? mat.rdry_in[s * mat.po + ti] : soil_dry<T>(tb, c[C_F1], c[C_F2], c[C_F3]);
     T fm[7] = {c[C_FM0], c[C_FM1], c[C_FM2], c[C_FM3], c[C_FM4], c[C_FM5], c[C_FM6]};
     T rwet;
-    soil_band<T>(tb, rdry, c[C_WET], fm, c[C_FMSUM], c[C_FILM2L], rwet);
+    if (HOIST_FILM) {
+      const T tw1 = film_same ? tw1s : soil_tw1<T>(tb, c[C_FILM2L]);      // (wave-uniform choice)
+      soil_band_tw<T>(tb, rdry, c[C_WET], fm, c[C_FMSUM], tw1, rwet);
+    } else {
+      soil_band<T>(tb, rdry, c[C_WET], fm, c[C_FMSUM], c[C_FILM2L], rwet);
+    }
     if (MAT && active) {
       if (mat.soil_refl) store_row<NT>(mat.soil_refl, off_f, rwet);
       if (!thermal && mat.soil_dry) store_row<NT>(mat.soil_dry, off_o, rdry);

@@ -213,10 +213,13 @@ __global__ __launch_bounds__(256, 2) void k_lut_scan_mfma(const float* __restric
         spart_f16v acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], bq[blk][kk], acc, 0, 0, 0);
-        float mn = __builtin_fminf(__builtin_fminf(acc[0], acc[1]), acc[2]);
+        // minimum of the 16 accumulator values: v_min3_f32 written out (fminf() makes the compiler canonicalise the MFMA
+        // results first, two v_max per block; v_min / v_min3 return the non-NaN operand whatever its kind)
+        float mn;
+        asm("v_min3_f32 %0, %1, %2, %3" : "=v"(mn) : "v"(acc[0]), "v"(acc[1]), "v"(acc[2]));
 #pragma unroll
-        for (int r = 3; r < 15; r += 2) mn = __builtin_fminf(__builtin_fminf(mn, acc[r]), acc[r + 1]);
-        mn = __builtin_fminf(mn, acc[15]);
+        for (int r = 3; r < 15; r += 2) asm("v_min3_f32 %0, %1, %2, %3" : "=v"(mn) : "v"(mn), "v"(acc[r]), "v"(acc[r + 1]));
+        asm("v_min_f32 %0, %1, %2" : "=v"(mn) : "v"(mn), "v"(acc[15]));
         // (best, sec) <- the two smallest of (best, sec, mn); a tile minimum EQUAL to the best so far becomes `sec`, so
         // an exact tie between tiles is seen by the reduce kernel
         const bool lt = mn < best[blk];

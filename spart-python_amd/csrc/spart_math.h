@@ -625,10 +625,13 @@ SPART_HD void leaf_band(const BandTab<T>& tb, T cab, T cca, T cdm, T cw, T cs, T
 
 // ------------------------------------------------------------------------------------------
 // BSM + soilwat, one band                                        (bsm.py:49-52, 99-124)
+// the water film's transmittance for one layer (:122 with k = 1; film2l = 2 film log2(e)): a function of the band and of
+// the film thickness only, so a kernel may evaluate it once for a run of samples that share the film thickness
+template <typename T> SPART_HD T soil_tw1(const BandTab<T>& tb, T film2l) { return Mx<T>::exp2(-film2l * tb.kw); }
+
 template <typename T>
-SPART_HD void soil_band(const BandTab<T>& tb, T rdry, T wet, const T fm[7], T fmsum16, T film2l, T& rwet) {
+SPART_HD void soil_band_tw(const BandTab<T>& tb, T rdry, T wet, const T fm[7], T fmsum16, T tw1, T& rwet) {
   T rbac = T(1) - (T(1) - rdry) * (rdry * tb.cbac + T(1) - rdry);  // :110-112
-  T tw1 = Mx<T>::exp2(-film2l * tb.kw);                            // :122 with k = 1; film2l = 2 film log2(e)
   // rwet = rdry f0 + sum_k f_k [Rw + (1-Rw)(1-p) x_k/(1 - p x_k)],  x_k = tw1^k rbac   (:123-124)
   // The six reciprocals 1/d_k, d_k = 1 - p x_k, come from ONE reciprocal of their product (prefix products
   // forward, peel-off backward): a v_rcp costs about five plain VALU ops in this instruction mix
@@ -652,6 +655,10 @@ SPART_HD void soil_band(const BandTab<T>& tb, T rdry, T wet, const T fm[7], T fm
   acc += fm[1] * x[0] * q;
   T v = rdry * fm[0] + tb.rw * fmsum16 + (T(1) - tb.rw) * (T(1) - tb.pw) * acc;
   rwet = (wet > T(0)) ? v : rdry;                                  // :102-103
+}
+template <typename T>
+SPART_HD void soil_band(const BandTab<T>& tb, T rdry, T wet, const T fm[7], T fmsum16, T film2l, T& rwet) {
+  soil_band_tw<T>(tb, rdry, wet, fm, fmsum16, soil_tw1<T>(tb, film2l), rwet);
 }
 
 template <typename T> SPART_HD T soil_dry(const BandTab<T>& tb, T f1, T f2, T f3) {
