@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collect the round's evidence on the GPU box (run through gpurun from the repo root):
-#   gpurun --timeout 1200 -- 'bash tools/collect_profiles.sh r2_a'
+#   gpurun --timeout 1200 -- 'bash tools/collect_profiles.sh r4_a'
 # Writes under gpurun_out/<tag>/ ; tools/ingest_profiles.py <tag> copies the summaries into profiles/.
 # Counter passes are their own runs (--kernel-trace + --pmc only), FETCH_SIZE and WRITE_SIZE apart (TCC slots).
 set -e -o pipefail
@@ -9,8 +9,8 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 SQ="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE"
-timeout -k 10 400 python $R/bench.py > $O/bench.json 2> $O/bench.err
-echo bench done
+# (the driver-style bench line is NOT taken here: bench.py reads the committed counter files of THIS collection, so it is run
+#  after tools/ingest_profiles.py -- tools/bench_after_ingest.sh -- and its roofline.issue.profiled_sources_match is true)
 cd /tmp && export TMPDIR=/tmp
 for DT in float32 float64; do
   ST=10; [ $DT = float64 ] && ST=5
@@ -47,6 +47,7 @@ timeout -k 10 120 python tools/prospect_bench.py 1000000 float32 5 >> $O/c2_benc
 timeout -k 10 300 python tools/mode_cost.py > $O/mode_cost.txt 2>&1
 timeout -k 10 300 python tools/lut_rate.py > $O/lut_rate.txt 2>&1
 timeout -k 10 300 python tools/lut_invert_rate.py > $O/lut_invert_rate.txt 2>&1
+timeout -k 10 300 bash tools/lut_profile.sh $TAG > $O/lut_profile.txt 2>&1
 timeout -k 10 300 python tools/mat_bench.py > $O/mat_bench.txt 2>&1
 timeout -k 10 300 python tools/fast_prelude_dev.py > $O/fast_prelude_dev.txt 2>&1
 # package power / clock while the materialised mode runs (it is power-bound: DESIGN.md section 4)
