@@ -346,16 +346,16 @@ def mode_records(torch, args, dev):
     # the contract of include/spart_hip.h (spart_materialize.fast_prelude), measured on the float64 columns of this table
     f64a = {k: v.clone() for k, v in eng.run(Pd, "float64", prune=True).items()}
     f64b = eng.run(Pd, "float64", prune=True, lidf="newton")
-    dev = {}
+    fdev = {}
     for k in f64a:
         d = (f64b[k] - f64a[k]).abs()
         rel = d / f64a[k].abs().clamp_min(1e-6)
         over = rel > 1e-6
-        dev[k] = {"max_abs": float(d.max().item()), "max_metric_floor1e-6": float(rel.max().item()),
+        fdev[k] = {"max_abs": float(d.max().item()), "max_metric_floor1e-6": float(rel.max().item()),
                   "p99.999_metric": float(torch.quantile(rel.flatten()[::7].float(), 0.99999).item()),
                   "entries_over_1e-6": int(over.sum().item()), "entries": int(rel.numel()),
                   "largest_value_among_them": float(f64a[k].abs()[over].max().item()) if bool(over.any()) else 0.0}
-    fp["float64_columns_vs_default"] = dev
+    fp["float64_columns_vs_default"] = fdev
     del f64a, f64b
     fp["workload"] = ("spart_materialize.fast_prelude = 1 (Engine.run(lidf='newton')): exact root of the LIDF equation + 8-point hot-spot "
                       "panels instead of the reference's stopped iteration; all 2162 bands evaluated; 1M spectra, fp32")
