@@ -462,12 +462,22 @@ class SPART:
         self.canopy = canopy
         self.atm = atm
         self.angles = angles
-        self.sensor = sensor
+        self.sensor = sensor                             # (property: loads sensorinfo; FileNotFoundError for unknown sensors, SPART.py:421-423)
         self.DOY = DOY
         self.dtype = dtype
         self.device = device
         self.spectral = SpectralBands()
-        self.sensorinfo = load_sensor_info(sensor)       # FileNotFoundError for unknown sensors (SPART.py:421-423)
+
+    @property
+    def sensor(self):
+        return self._sensor
+
+    @sensor.setter
+    def sensor(self, sensor):
+        # The reference's setter (SPART.py:146-149) only flags the change and keeps the sensorinfo of the constructor, so a
+        # re-used object mixes two sensors; a FRESH object -- the parity target -- has the sensorinfo of its sensor.
+        self.sensorinfo = load_sensor_info(sensor)
+        self._sensor = sensor
 
     def _columns(self):
         return (self.leafbio.columns() + self.soilpar.columns() + self.canopy.columns() + self.angles.columns()

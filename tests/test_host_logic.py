@@ -32,6 +32,22 @@ def test_constructor_surface_matches_reference():
     from SPART.smac import SMAC, AtmosphericProperties  # noqa: F401
 
 
+def test_changing_the_sensor_reloads_its_tables():
+    """sp.sensor = ... on an existing object behaves like a fresh object of that sensor (band centres, band ids, SMAC
+    coefficients follow); an unknown name raises FileNotFoundError like the reference's loader (SPART.py:421-423) and
+    leaves the object as it was."""
+    import SPART
+    sp = SPART.SPART(SPART.SoilParameters(0.5, 0, 100, 15, 25, 0.015), SPART.LeafBiology(40, 0.01, 0.02, 0, 10, 10, 1.5),
+                     SPART.CanopyStructure(3, -0.35, -0.15, 0.05), SPART.AtmosphericProperties(0.3246, 0.3480, 1.4116, 1013.25),
+                     SPART.Angles(40, 0, 0), "Sentinel2A-MSI", 100)
+    assert len(sp.sensorinfo["band_id_smac"]) == 13
+    sp.sensor = "TerraAqua-MODIS"
+    assert sp.sensor == "TerraAqua-MODIS" and len(sp.sensorinfo["band_id_smac"]) == 20
+    with pytest.raises(FileNotFoundError):
+        sp.sensor = "Sentinel9Z"
+    assert sp.sensor == "TerraAqua-MODIS" and len(sp.sensorinfo["band_id_smac"]) == 20
+
+
 def test_spectral_bands_and_loaders():
     import SPART
     sb = SPART.SpectralBands()
