@@ -107,6 +107,29 @@ void hm_lidf_dcum(int mode, int64_t n, const double* a, const double* b, double*
     }
 }
 
+// hot-spot integrals (sailh.py:115-135): taken[i] = 1 where the closed-form series applies (hotspot_series); ser (n,2) its
+// two integrals; pan (n,2) the Gauss-Legendre panels with one halving MORE than the kernel uses (a tighter reference) and the
+// below-canopy stretch in two panels
+void hm_hotspot(int64_t n, const double* K, const double* k, const double* LAI, const double* q, const double* dso, int* taken,
+                double* ser, double* pan) {
+  const double dx = 1.0 / NLAYER;
+  for (int64_t i = 0; i < n; ++i) {
+    PsoFn f;
+    f.hot = false;
+    f.alpha = (dso[i] / q[i]) * 2.0 / (k[i] + K[i]);
+    f.A = (K[i] + k[i]) * LAI[i];
+    f.C = std::sqrt(K[i] * k[i]) * LAI[i] / f.alpha;
+    ser[2 * i] = ser[2 * i + 1] = 0.0;
+    taken[i] = hotspot_series(f.A, f.C, f.alpha, ser[2 * i], ser[2 * i + 1]) ? 1 : 0;
+    double rate = std::fmax(f.alpha, f.A + std::sqrt(K[i] * k[i]) * LAI[i]), hw = 1.0, tot = 0.0, lo = -1.0;
+    int m = 0;
+    while (rate * hw > 1.0 && m < 44) { hw *= 0.5; ++m; }
+    for (int j = 0; j < m; ++j) { tot += gl_panel<false>(f, lo, 0.5 * lo); lo *= 0.5; }
+    pan[2 * i] = tot + gl_panel<false>(f, lo, 0.0);
+    pan[2 * i + 1] = (gl_panel<false>(f, -1.0 - dx, -1.0 - 0.5 * dx) + gl_panel<false>(f, -1.0 - 0.5 * dx, -1.0)) / dx;
+  }
+}
+
 void hm_log1p(int dtype, int64_t n, const double* x, double* out) {
   for (int64_t i = 0; i < n; ++i) out[i] = dtype == 0 ? (double)Mx<float>::log1p((float)x[i]) : Mx<double>::log1p(x[i]);
 }

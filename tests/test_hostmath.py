@@ -128,6 +128,27 @@ def test_hotspot_integrals_cover_small_q(hm, tab, oracle, tables):
     assert rel_err(toa[:, :, 0], ref["R_TOC"], 1e-3) < 1e-8
 
 
+def test_hotspot_series_against_refined_panels(hm):
+    """The closed-form hot-spot integrals of the prelude (spart_math.h hotspot_series: Kummer's series of the incomplete gamma
+    function, used when C <= 8 and A + alpha >= 2) against Gauss-Legendre panels refined one level beyond the kernel's, over
+    log-uniform geometries far wider than the benchmark's (LAI 0.003 ... 8, q 0.001 ... 0.25, dso 0.001 ... 5): <= 1e-13 relative on
+    both integrals (the reference's QUADPACK is good to ~1e-13); and inside the benchmark's ranges nearly every sample takes it."""
+    rng = np.random.default_rng(11)
+    n = 200_000
+    K, k = rng.uniform(0.4, 3.0, n), rng.uniform(0.4, 3.0, n)
+    LAI, q, dso = 10 ** rng.uniform(-2.5, 0.9, n), 10 ** rng.uniform(-3, -0.6, n), 10 ** rng.uniform(-3, 0.7, n)
+    taken = np.zeros(n, dtype=np.int32)
+    ser, pan = np.zeros((n, 2)), np.zeros((n, 2))
+    hm.hm_hotspot(ctypes.c_int64(n), dp(K), dp(k), dp(LAI), dp(q), dp(dso), taken.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), dp(ser), dp(pan))
+    t = taken == 1
+    assert 0.4 < t.mean() < 0.9
+    assert np.max(np.abs(ser[t] / pan[t] - 1.0)) < 1e-13
+    LAI, q, dso = rng.uniform(0.1, 7, n), rng.uniform(0.01, 0.2, n), rng.uniform(0.05, 2.5, n)      # the benchmark's ranges
+    hm.hm_hotspot(ctypes.c_int64(n), dp(K), dp(k), dp(LAI), dp(q), dp(dso), taken.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), dp(ser), dp(pan))
+    t = taken == 1
+    assert t.mean() > 0.9 and np.max(np.abs(ser[t] / pan[t] - 1.0)) < 1e-13
+
+
 def test_lidf_jump_reproduces_the_literal_iteration(hm, oracle):
     """The cumulative LIDF of the float64 prelude: the reference's fixed-point iteration with its |dx| > 1e-8 stopping rule
     (sailh.py:378-382), (0) in the x-form with library sin / cos, (1) in u = x - 2 theta with the Taylor rotation,
