@@ -25,7 +25,9 @@
  *     that run concurrently on the GPU (different streams) need different workspaces; if two streams do pass the
  *     same workspace, the later call is ordered after the earlier one (hipStreamWaitEvent on its completion) -- slow,
  *     never a race -- or fails with SPART_ERR_INVALID when that order cannot be expressed (e.g. across a stream
- *     capture).  HIP-graph REPLAYS are outside the library's view: a captured call's workspace belongs to its graph;
+ *     capture).  HIP-graph REPLAYS are outside the library's view: a captured call's workspace belongs to its graph.  The
+ *     first call on a stream (and the first use of a workspace on it) creates that stream's side stream / events: issue
+ *     one ordinary call on the stream before capturing it, so that the capture itself creates nothing;
  *   - return value 0 = ok, <0 = error (spart_last_error gives the text).  Numerical trouble
  *     propagates as NaN/inf exactly like the reference (no clamping).
  */
