@@ -563,20 +563,6 @@ static LutLayout lut_layout(int dtype, int64_t B, int nb, int64_t M) {
 static double lut_coef_ef(int nb, int kfma, double u) { return (3.0 * nb + 2.0 * kfma + 16.0) * 1.01 * u; }
 static double lut_coef_e(int nb, int kfma, double u) { return (nb + 2.0 * kfma + 10.0) * 1.01 * u; }
 
-// Unused dynamic LDS per workgroup of the float32 scan: 54 KB leaves room for TWO workgroups per CU (2 waves per SIMD).
-// The exact-f32 matrix instruction sustains 30.0 ns per MFMA and SIMD with two waves issuing it and 34.7 ns with four
-// (tools/ubench/mfma_f32_rate.hip, profiles/r4_ubench_mfma_f32_rate.txt); the scan, whose registers would allow four,
-// measured 15.31 / 15.06 / 14.92 ms with 4 / 3 / 2 resident workgroups (profiles/r4_lut_lds_pad_sweep.txt).  The float64
-// instruction behaves the other way round (28.4 ns with four waves, 30.4 with two) and keeps its natural occupancy.
-// Only for KS = 7, 8 (12 ... 15 bands: Sentinel-2): with KS = 4 the tiles are too short to hide the vector work behind the
-// matrix pipe with two waves (nb = 6: 9.25 -> 9.94 ms), with KS = 11 it is a wash (21.9 -> 22.3 ms).
-// SPART_LUT_LDS_PAD overrides the value for every KS (experiments).
-static size_t lut_scan_lds_pad(int ks) {
-  static const long forced = [] { const char* e = std::getenv("SPART_LUT_LDS_PAD"); return e ? std::atol(e) : -1L; }();
-  if (forced >= 0) return (size_t)forced;
-  return (ks == 7 || ks == 8) ? (size_t)(54 * 1024) : (size_t)0;
-}
-
 template <typename T>
 static int lut_impl(spart_ctx* ctx, int dtype, int64_t B, int nb, const void* lut_, int64_t M, const void* obs_,
                     const void* weights, int64_t* best_idx, void* best_cost, char* wsp, hipStream_t st) {
@@ -600,7 +586,7 @@ static int lut_impl(spart_ctx* ctx, int dtype, int64_t B, int nb, const void* lu
   case K:                                                                                                                  \
     hipLaunchKernelGGL((k_lut_prep<float, K, 32>), gprep, dim3(256), 0, st, lut, w, (const float*)centre, nb, B, L.ntile,  \
                        tiles, ctl);                                                                                        \
-    hipLaunchKernelGGL((k_lut_scan_mfma<K>), grid, dim3(256), lut_scan_lds_pad(K), st, (const float*)tiles, obs, w, (const float*)centre,    \
+    hipLaunchKernelGGL((k_lut_scan_mfma<K>), grid, dim3(256), 0, st, (const float*)tiles, obs, w, (const float*)centre,    \
                        nb, L.ntile, M, L.nslice, pc, ps, pt);                                                              \
     break;
     switch (L.ks) { SPART_LUT_KS(4) SPART_LUT_KS(7) SPART_LUT_KS(8) SPART_LUT_KS(11) SPART_LUT_KS(16) }

@@ -75,7 +75,16 @@ template <> struct LutNum<double> {
 constexpr int LUT_CTL_WORDS = 2;
 constexpr int LUT_CENTRE_ROWS = 8192;      // rows sampled for the column means
 constexpr int LUT_FB_BLOCKS = 2048;        // workgroups (x 4 waves) of the brute-force fallback
-constexpr int LUT_TO = 4;                  // float32 scan: 32-observation blocks per wave (128 observations, 4 KS operand registers)
+// float32 scan: 32-observation blocks per wave (256 observations, 8 KS operand registers + 8 x 16 accumulators: 106 ... 226
+// VGPRs for KS = 4 ... 16).  Eight independent accumulator chains per wave keep the matrix pipe fed from TWO or three resident
+// waves per SIMD -- v_mfma_f32_32x32x2_f32 sustains 27.2 ns per instruction and SIMD (154 Tflop/s) with two issuing waves
+// and 33.9 ns with four (tools/ubench/mfma_f32_rate2.hip) -- and every LUT tile loaded is used for twice the observations.
+// Measured 1M x 65 536, nb = 13: 4 / 6 / 7 / 8 / 10 / 12 / 16 blocks: 15.25 / 15.24 / 15.11 / 14.45 / 15.46 / 15.71 / 14.97 ms
+// (profiles/r4_lut_to_sweep2.txt); nb = 6: 9.25 -> 9.10 ms, nb = 21: unchanged.
+#ifndef SPART_LUT_TO
+#define SPART_LUT_TO 8
+#endif
+constexpr int LUT_TO = SPART_LUT_TO;
 
 // column means of a strided sample (finite entries only) -> centre[nb]; also resets the control words
 template <typename T>
@@ -159,7 +168,7 @@ __global__ __launch_bounds__(256) void k_lut_prep(const T* __restrict__ lut, con
 
 // float32 scan on the exact-f32 matrix cores.  A 32 x 32 x 2 MFMA takes ONE register of A (lane l: row l % 32,
 // k = l / 32) and one of Bq (lane l: column l % 32, k = l / 32); K = 2 KS is covered by KS of them chained on one
-// 16-register accumulator (lane l ends up with 16 LUT rows of observation l % 32).  Each wave keeps LUT_TO blocks of 32
+// 16-register accumulator (lane l ends up with 16 LUT rows of observation l % 32).  Each wave keeps LUT_TO = 8 blocks of 32
 // observations in registers (LUT_TO x KS operand registers) and streams the LUT tiles of its slice past them.
 // The matrix pipe does the arithmetic (KS x 64 cycles per 1024 comparisons); the vector ALU only takes the minimum of
 // the 16 accumulator values (v_min3) and keeps, per lane, the smallest and second smallest of those tile minima and
