@@ -38,3 +38,19 @@ if __name__ == "__main__":
     for r, a, b in zip(rows, rel[rows].max(axis=1), relq.max(axis=1)):
         print(f"  row {r}: vs oracle(gl) {a:.2e}   vs oracle(QUADPACK) {b:.2e}   q = {P[r, 18]:.4f} LAI = {P[r, 15]:.2f}")
     print(f"the 24 worst rows against the QUADPACK route: max {relq.max():.3e}")
+    # dissect the worst row: which band, how large is the entry, which stage deviates (full oracle spectra vs materialised HIP spectra)
+    r = int(rows[0])
+    full = O.spart_run(P[r:r + 1], "Sentinel2A-MSI", T, pso="quad", full=True)
+    eng = get_engine("Sentinel2A-MSI", 0)
+    fields = ("leaf_refl", "leaf_tran", "soil_refl", "rso", "rdo", "rsd", "rdd")
+    hip = eng.run(torch.as_tensor(P[r:r + 1].T.copy(), device="cuda:0"), "float64", materialize=fields)
+    j = int(np.argmax(rel[r]))
+    print(f"worst row {r}: band {j}, R_TOC oracle {ref[r, j]:.6e} HIP {got[r, j]:.6e} abs diff {abs(got[r, j] - ref[r, j]):.2e}")
+    print("   parameters:", dict(zip(workloads.PARAM_NAMES, [float(f'{x:.5g}') for x in P[r]])))
+    rho, tau = O.pad_leaf(full["leaf_refl"], full["leaf_tran"])
+    exp = dict(leaf_refl=rho, leaf_tran=tau, soil_refl=O.pad_soil(full["soil_refl"]), rso=full["rso"], rdo=full["rdo"], rsd=full["rsd"], rdd=full["rdd"])
+    for k in fields:
+        a, b = hip[k].cpu().numpy()[0], exp[k][0]
+        d = np.abs(a - b)
+        i = int(np.argmax(d / np.maximum(np.abs(b), 1e-12)))
+        print(f"   {k:10s} max abs {d.max():.2e} at band {int(np.argmax(d))}; max rel {np.max(d / np.maximum(np.abs(b), 1e-12)):.2e} at band {i} (value {b[i]:.3e})")
