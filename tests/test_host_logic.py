@@ -220,3 +220,30 @@ def test_calculate_tav_host_entry_point(oracle, tables):
             assert a.shape == nr.shape and np.max(np.abs(a / b - 1)) < 1e-12, alpha
     assert isinstance(SPART.calculate_tav(90, 2.0), float) and abs(SPART.calculate_tav(90, 2.0) / oracle.calculate_tav(90, 2.0) - 1) < 1e-13
     assert calculate_tav(40, np.full((3, 2), 1.4)).shape == (3, 2)
+
+
+def test_lut_brute_force_checkers_agree():
+    """tools/lut_brute_force.py: the numpy and the eager-torch loops of the DEFINED cost of spart_lut_nearest (sequential, in
+    the dtype, first index on ties = the reference's np.argmin rule, SPART.py:381-387) give bit-identical indices and costs on
+    the CPU -- weighted / unweighted, NaN row, duplicate rows, NaN observation, both dtypes, several block sizes."""
+    import os
+    import sys
+    import torch
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from lut_brute_force import brute_force_numpy, brute_force_torch
+    rng = np.random.default_rng(0)
+    for dt in (np.float32, np.float64):
+        for nb in (1, 3, 13):
+            lut = rng.uniform(0, 0.6, (3000, nb)).astype(dt)
+            lut[17] = np.nan
+            lut[40] = lut[7]
+            obs = (lut[rng.integers(18, 3000, 120)] + rng.normal(0, 0.01, (120, nb))).astype(dt)
+            obs[:3] = lut[[7, 40, 100]]
+            obs[5, 0] = np.nan
+            for w in (None, rng.uniform(0.5, 2, nb).astype(dt)):
+                i1, c1 = brute_force_numpy(lut, obs, w)
+                for block in (1000, 50_000, 1 << 27):
+                    i2, c2 = brute_force_torch(torch.tensor(lut), torch.tensor(obs), None if w is None else torch.tensor(w), max_elems=block)
+                    assert np.array_equal(i1, i2.numpy()) and np.array_equal(c1, c2.numpy()), (dt, nb, block)
+                assert i1[0] == 7 and i1[1] == 7 and i1[5] == -1 and np.isinf(c1[5]) and c1[0] == 0
