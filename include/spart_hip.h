@@ -18,13 +18,15 @@
  *   - spectra and result columns are row-major (B, nbands), band-contiguous, in `dtype`; the row pitch of the
  *     2162- / 2001-wide spectrum arrays is the row width unless spart_ctx_set_row_pitch says otherwise;
  *   - `stream` is a hipStream_t (NULL = default stream); calls are asynchronous on it (spart_run_batch may run some
- *     of its kernels on a side stream the context owns -- one per caller stream -- and joins them back into `stream`
- *     before it returns, so the caller sees plain stream semantics, HIP-graph capture included);
+ *     of its kernels on a side stream the context owns -- one per caller stream, for the first 32 caller streams a context
+ *     sees; calls on further streams run every kernel on `stream` itself: same results, no overlap -- and joins them back
+ *     into `stream` before it returns, so the caller sees plain stream semantics, HIP-graph capture included);
  *   - a context is THREAD-SAFE: its tables are immutable after creation and the little per-call state it has (side
  *     streams, events) is guarded, so any number of host threads may call into one context on any streams.  Calls
  *     that run concurrently on the GPU (different streams) need different workspaces; if two streams do pass the
  *     same workspace, the later call is ordered after the earlier one (hipStreamWaitEvent on its completion) -- slow,
- *     never a race -- or fails with SPART_ERR_INVALID when that order cannot be expressed (e.g. across a stream
+ *     never a race, for any number of (workspace, stream) pairs: the context remembers every use until it has seen
+ *     it complete -- or fails with SPART_ERR_INVALID when that order cannot be expressed (e.g. across a stream
  *     capture).  HIP-graph REPLAYS are outside the library's view: a captured call's workspace belongs to its graph.  The
  *     first call on a stream (and the first use of a workspace on it) creates that stream's side stream / events: issue
  *     one ordinary call on the stream before capturing it, so that the capture itself creates nothing;
@@ -196,8 +198,10 @@ int spart_run_batch(spart_ctx *ctx, int dtype, int64_t B, const double *const pa
  * where c is evaluated in `dtype` as  c = 0; for j ascending: d = lut[b,j] - obs[m,j]; c = c + (w_j * d) * d  with every
  * operation rounded to `dtype` and no fused multiply-add.  best_idx (M,) int64 = the LOWEST row index attaining the minimum
  * of that c (bit-exact: the same answer as a brute-force loop, in both dtypes, for any nb), best_cost (M,) = that minimum
- * (divide by nb and take the root for an RMSE).  Rows or observations whose cost is NaN / +inf never win (-1 / +inf when no
- * row has a finite cost).
+ * (divide by nb and take the root for an RMSE).  Rows or observations whose cost is not finite -- NaN, +inf, or -inf (negative
+ * weights with overflowing products) -- never win (-1 / +inf when no row has a finite cost); so does a LUT row that holds a
+ * non-finite value or whose centred weighted norm sum_j |w_j| (lut[b,j] - centre_j)^2 overflows `dtype` (values near the
+ * largest finite number), even if its cost against a particular observation would be finite.
  * How: a GEMM with K = nb + 1 on the matrix cores -- exact-f32 v_mfma_f32_32x32x2_f32 for SPART_F32,
  * v_mfma_f64_16x16x4_f64 for SPART_F64 -- over the CENTRED LUT (per-band mean removed) ranks the tiles of 32 / 16 LUT rows by
  * |x'|^2 - 2 x'.y'; every tile whose minimum lies within a proven rounding bound of the best one is then evaluated row by
@@ -224,6 +228,27 @@ int spart_lut_stats(spart_ctx *ctx, int dtype, int64_t B, int nb, int64_t M, con
 int spart_profile_enable(spart_ctx *ctx, int max_calls);
 int spart_profile_read(spart_ctx *ctx, double *total_ms, int *ncalls);
 int spart_profile_read_stages(spart_ctx *ctx, double stage_ms[SPART_NSTAGE], int *ncalls);
+
+/* Knobs.  None of them changes a result (the one exception is marked); defaults are what every number in DESIGN.md was
+ * measured with.
+ *   environment, read by the library:
+ *     SPART_ROCTX=1          push / pop ROCTX ranges around the stages of spart_run_batch when a roctx library can be dlopen'ed
+ *     SPART_SIDE_STREAM=0    read at spart_ctx_create: run the column kernels on the caller's stream instead of a side stream
+ *     SPART_CHUNK=<n>        samples per workgroup of the band kernels (tuning sweeps; default: chosen from B)
+ *   environment, read by the Python loader / build script (spart_amd/_lib.py, build.py):
+ *     SPART_HIP_LIB=<path>   load another build of this ABI (A/B timing, tools/ab_bench.py)
+ *     SPART_FAST_MATH=0      build with IEEE division / libm transcendentals instead of v_rcp / v_exp / v_log + Newton steps
+ *                            (CHANGES results at the 1e-15 (float64) / 1e-7 (float32) level; parity is tested with the default)
+ *   compile-time macros (A/B variants built through build.py's `extra` flags, which are hashed into spart_build_id):
+ *     SPART_PRELUDE_WAVES (3)   occupancy the prelude kernel is compiled for
+ *     SPART_HOIST_FILM          hoist the water-film transmittance out of the sample loop (default: float64 kernels only)
+ *     SPART_FRESH_COEF (1)      re-materialise the plate-model polynomial coefficients per use instead of holding them in VGPRs
+ *     SPART_LIDF_JUMP (1)       skip ahead in the LIDF fixed-point iteration by its contraction rate (same iterate sequence end)
+ *     SPART_HOTSPOT_SERIES (1)  closed-form series for the hot-spot integrals where it converges, panels elsewhere
+ *     SPART_LUT_TO (8)          observation blocks per wave of the float32 LUT scan
+ *     SPART_EXPERIMENT          1 / 2: arithmetic-only / store-only measurement variants of k_prospect (tools/prospect_split.sh).
+ *                               NOT a product configuration: variant 2 does not compute leaf spectra.  Never defined by build.py.
+ */
 
 #ifdef __cplusplus
 }

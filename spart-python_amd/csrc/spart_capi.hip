@@ -29,10 +29,11 @@ struct WsUse {
   size_t bytes = 0;
   hipStream_t stream = nullptr;
   hipEvent_t done = nullptr;
-  uint64_t stamp = 0;
+  bool captured = false;             // `done` was recorded into a stream capture: it orders nothing outside that graph
 };
-constexpr size_t MAX_LANES = 32;     // caller streams with their own side stream (further streams run the columns in line)
-constexpr size_t MAX_WS_USES = 16;   // (workspace, stream) pairs remembered
+constexpr size_t MAX_LANES = 32;     // caller streams with their own side stream (further streams run the columns in line;
+                                     // stated in include/spart_hip.h)
+constexpr size_t WS_PRUNE_AT = 16;   // (workspace, stream) records kept before completed ones are looked for and recycled
 
 struct spart_ctx {
   int device = 0;
@@ -62,7 +63,6 @@ struct spart_ctx {
   // still owned by a call on ANOTHER stream is ordered after it (hipStreamWaitEvent), so sharing one workspace between
   // streams is slow but never a race; if the order cannot be expressed the call fails with SPART_ERR_INVALID.
   std::vector<WsUse> ws_uses;
-  uint64_t stamp = 0;
   // optional timing of the dominant kernel (k_bands): event pairs recorded on the caller's stream
   bool profile = false;
   std::vector<hipEvent_t> ev;   // NEV events per timed call (run_impl)
@@ -174,31 +174,42 @@ int ws_acquire(spart_ctx* ctx, const char* base, size_t bytes, hipStream_t st, c
   }
   return SPART_OK;
 }
-// After a call's last launch: remember (range, stream) and record its completion event.
+// After a call's last launch: remember (range, stream) and record its completion event.  A record is only ever recycled
+// when the use it stands for HAS COMPLETED (hipEventQuery) or can order nothing (its event went into a stream capture);
+// while every remembered use is still in flight the list simply grows -- there is no cap that could drop a live one.
 int ws_release(spart_ctx* ctx, const char* base, size_t bytes, hipStream_t st, const char* who) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+  const bool capturing = cs != hipStreamCaptureStatusNone;
   WsUse* slot = nullptr;
   for (WsUse& u : ctx->ws_uses)
-    if (u.base == base && u.stream == st) slot = &u;
-  if (!slot) {
-    if (ctx->ws_uses.size() < MAX_WS_USES) {
-      WsUse u;
-      if (hipEventCreateWithFlags(&u.done, hipEventDisableTiming) != hipSuccess) {
-        (void)hipGetLastError();
-        return fail(ctx, SPART_ERR_HIP, "%s: cannot create the workspace completion event", who);
+    if (u.base == base && u.stream == st) slot = &u;      // same pair again: the stream orders the two uses itself
+  if (!slot && ctx->ws_uses.size() >= WS_PRUNE_AT) {
+    for (WsUse& u : ctx->ws_uses) {
+      // (no event query while this stream is being captured: in a global-mode capture that call is itself illegal)
+      bool idle = u.captured;
+      if (!idle && !capturing) {
+        const hipError_t q = hipEventQuery(u.done);
+        if (q == hipSuccess) idle = true;
+        else (void)hipGetLastError();                     // hipErrorNotReady (or anything else): treat as in flight
       }
-      ctx->ws_uses.push_back(u);
-      slot = &ctx->ws_uses.back();
-    } else {                                   // reuse the least recently used record (and its event)
-      slot = &ctx->ws_uses[0];
-      for (WsUse& u : ctx->ws_uses)
-        if (u.stamp < slot->stamp) slot = &u;
+      if (idle) { slot = &u; break; }
     }
-    slot->bytes = 0;
+    if (slot) slot->bytes = 0;
+  }
+  if (!slot) {
+    WsUse u;
+    if (hipEventCreateWithFlags(&u.done, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(ctx, SPART_ERR_HIP, "%s: cannot create the workspace completion event", who);
+    }
+    ctx->ws_uses.push_back(u);
+    slot = &ctx->ws_uses.back();
   }
   slot->base = base;
   slot->bytes = bytes > slot->bytes ? bytes : slot->bytes;
   slot->stream = st;
-  slot->stamp = ++ctx->stamp;
+  slot->captured = capturing;
   const hipError_t e = hipEventRecord(slot->done, st);
   if (e != hipSuccess) return fail(ctx, SPART_ERR_HIP, "%s: recording the workspace completion event: %s", who, hipGetErrorString(e));
   return SPART_OK;
@@ -803,7 +814,7 @@ int spart_ctx_create(spart_ctx** out, int device, const spart_tables* t) {
     const char* e = std::getenv("SPART_SIDE_STREAM");            // "0" keeps every kernel on the caller's stream
     ctx->side_enabled = !(e && e[0] == '0');
     ctx->lanes.reserve(MAX_LANES);                                // (pointers into the vector stay valid)
-    ctx->ws_uses.reserve(MAX_WS_USES);
+    ctx->ws_uses.reserve(WS_PRUNE_AT);
   }
   *out = ctx;
   return SPART_OK;

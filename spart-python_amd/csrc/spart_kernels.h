@@ -69,6 +69,33 @@ __device__ __forceinline__ void stage_constants(T* lds_c, const T* __restrict__ 
   }
 }
 
+// The same copy in two halves -- global loads into registers, registers into LDS -- for the double-buffered band kernel: the
+// loads of the NEXT 32 samples are in flight while the current 32 are evaluated.
+// (SUB samples per copy: TILE / SUB rows of the block per pass, NCONST * SUB / TILE values per lane.)
+template <typename T, int SUB>
+__device__ __forceinline__ void stage_fetch(T (&r)[NCONST * SUB / TILE], const T* __restrict__ blk, int64_t Bp, int nsub) {
+  constexpr int RP = TILE / SUB;
+  static_assert(TILE % SUB == 0 && NCONST % RP == 0, "whole passes");
+  const int si = threadIdx.x % SUB, i0 = threadIdx.x / SUB;
+  const unsigned lane_off = ((unsigned)i0 * (unsigned)Bp + (unsigned)si) * (unsigned)sizeof(T);
+  if (si < nsub) {
+#pragma unroll
+    for (int k = 0; k < NCONST / RP; ++k) {
+      const T* row = blk + (int64_t)(RP * k) * Bp;
+      r[k] = *reinterpret_cast<const T*>(reinterpret_cast<const char*>(row) + lane_off);
+    }
+  }
+}
+template <typename T, int SUB>
+__device__ __forceinline__ void stage_put(T* lds_c, const T (&r)[NCONST * SUB / TILE], int nsub) {
+  constexpr int RP = TILE / SUB;
+  const int si = threadIdx.x % SUB, i0 = threadIdx.x / SUB;
+  if (si < nsub) {
+#pragma unroll
+    for (int k = 0; k < NCONST / RP; ++k) lds_c[si * NCONST + i0 + RP * k] = r[k];
+  }
+}
+
 // K1: one lane per sample, float64: parameters -> band constants + atmosphere scalars.
 // FAST: Newton LIDF + 8-point hot-spot panels (~1e-7 from the literal forms; only the legacy float32-columns mode),
 // otherwise the reference's own LIDF iteration and 16-point panels.  The constants are computed in float64 and
@@ -229,17 +256,42 @@ void k_bands(const T* __restrict__ tab, const T* __restrict__ cst, int64_t Bp, i
   // land in VGPRs: on gfx950 a VALU op with an SGPR source issues ~1.6x slower than with VGPR / literal sources
   // (profiles/r1_ubench_valu_issue.txt), and ~60 ops per band use these constants -- the same kernel with
   // scalar loads (s_load_dwordx8 -> SGPR operands) is 6 % slower.
-  constexpr int SUB = 32;
+#ifndef SPART_BANDS_SUB
+#define SPART_BANDS_SUB 32
+#endif
+  constexpr int SUB = SPART_BANDS_SUB;                 // (64 needs PINGPONG: the single-buffer copy is written for 32)
 #ifndef SPART_HOIST_FILM
 #define SPART_HOIST_FILM (sizeof(T) == 8)
 #endif
   constexpr bool HOIST_FILM = SPART_HOIST_FILM;
-  __shared__ __attribute__((aligned(16))) T lds_c[SUB * NCONST];
+  // Double-buffered staging (PINGPONG): the global loads of the next 32 samples' constants are issued BEFORE the sample loop
+  // and land in LDS after it, so a workgroup meets ONE barrier per 32 samples and never waits for memory on its critical
+  // path (single buffer: barrier, load, wait, barrier).  Five more VGPRs per lane (float32) while the loop runs.
+#ifndef SPART_BANDS_PINGPONG
+#define SPART_BANDS_PINGPONG (sizeof(T) == 4 && MAT == 0)
+#endif
+  constexpr bool PINGPONG = SPART_BANDS_PINGPONG;
+  __shared__ __attribute__((aligned(16))) T lds_all[(PINGPONG ? 2 : 1) * SUB * NCONST];
+  static_assert(PINGPONG || SUB == 32, "stage_constants copies 32 samples");
+  T stg[NCONST * SUB / TILE];
+  int cur = 0;
+  if (PINGPONG) {
+    const int n0 = (int)((s1 - s0 < SUB) ? (s1 - s0) : SUB);
+    stage_fetch<T, SUB>(stg, cst + s0, Bp, n0);
+    stage_put<T, SUB>(lds_all, stg, n0);
+    __syncthreads();
+  }
   for (int64_t sb = s0; sb < s1; sb += SUB) {
   const int nsub = (int)((s1 - sb < SUB) ? (s1 - sb) : SUB);
-  __syncthreads();                                     // the previous sub-chunk has been consumed by every wave
-  stage_constants<T>(lds_c, cst + sb, Bp, nsub);
-  __syncthreads();
+  T* const lds_c = lds_all + cur * (SUB * NCONST);
+  const int nnext = (int)((s1 - sb - SUB < SUB) ? (s1 - sb - SUB) : SUB);      // (<= 0: this is the last sub-chunk)
+  if (PINGPONG) {
+    if (nnext > 0) stage_fetch<T, SUB>(stg, cst + sb + SUB, Bp, nnext);
+  } else {
+    __syncthreads();                                   // the previous sub-chunk has been consumed by every wave
+    stage_constants<T>(lds_c, cst + sb, Bp, nsub);
+    __syncthreads();
+  }
   // The water film's single-layer transmittance exp2(-film2l kw) depends on the band and the film thickness only.  LUTs
   // are usually generated with ONE film thickness (BASELINE configs 3-5 fix it), so when the samples staged here all share
   // it the lane evaluates it once per 32 samples instead of once per sample (same value: the same function of the same
@@ -341,6 +393,11 @@ void k_bands(const T* __restrict__ tab, const T* __restrict__ cst, int64_t Bp, i
       off_f += (unsigned)mat.pf * (unsigned)sizeof(T);
       off_o += (unsigned)mat.po * (unsigned)sizeof(T);
     }
+  }
+  if (PINGPONG) {
+    if (nnext > 0) stage_put<T, SUB>(lds_all + (cur ^ 1) * (SUB * NCONST), stg, nnext);
+    __syncthreads();            // everyone is done with this buffer (it is refilled one sub-chunk from now) and sees the other
+    cur ^= 1;
   }
   }
   if (FULL == 2) {
@@ -474,16 +531,22 @@ __global__ __launch_bounds__(TILE) void k_prospect(const T* __restrict__ tab, co
   if (o_kchl) o_kchl += s0 * po;
   for_samples_staged<T, sizeof(T) == 4>(cst, Bp, s0, s1, [&](int64_t, auto c) {
     T refl, tran, absb, K;
-#if defined(SPART_X_STOREONLY)
+#ifndef SPART_EXPERIMENT
+    leaf_band<T>(tb, c[C_CAB], c[C_CCA], c[C_CDM], c[C_CW], c[C_CS], c[C_CANT], c[C_CBC], c[C_PROT], c[C_NM1], refl,
+                 tran, absb, K);
+    if (active) {
+#else
+    // MEASUREMENT VARIANTS, never part of a product build (tools/prospect_split.sh builds them with
+    // build.py's `extra` flags, which are hashed into spart_build_id; nothing else defines the macro):
+    // SPART_EXPERIMENT = 1 arithmetic only (the stores sit behind a test no value passes), = 2 stores only (placeholder
+    // arithmetic -- NOT leaf spectra).  profiles/r4_prospect_split.txt is what they measured.
+#if SPART_EXPERIMENT == 2
     refl = c[C_CAB] * tb.kab; tran = c[C_CW] * tb.kw; K = c[C_CDM] + tb.kdm; absb = 0;
 #else
     leaf_band<T>(tb, c[C_CAB], c[C_CCA], c[C_CDM], c[C_CW], c[C_CS], c[C_CANT], c[C_CBC], c[C_PROT], c[C_NM1], refl,
                  tran, absb, K);
 #endif
-#if defined(SPART_X_NOSTORE)
-    if (active && refl + tran + K == T(-12345.678)) {
-#else
-    if (active) {
+    if (active && (SPART_EXPERIMENT != 1 || refl + tran + K == T(-12345.678))) {
 #endif
       if (o_refl) store_row<NT>(o_refl, off, refl);
       if (o_tran) store_row<NT>(o_tran, off, tran);

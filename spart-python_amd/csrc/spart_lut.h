@@ -331,7 +331,8 @@ __global__ __launch_bounds__(256, 2) void k_lut_scan_mfma64(const double* __rest
 // coef = 2 (3 nb + 2 K + 16) * 1.01 * u (host: lut_delta_coef).
 template <typename T>
 __device__ __forceinline__ bool lut_better(T oc, int64_t oi, T bc, int64_t bi) {     // (cost, row) lexicographic; (inf, -1) is worst
-  return oc < bc || (oc == bc && oi >= 0 && oi < bi);
+  // a cost of -inf (negative weights whose products overflow) is NOT FINITE and never wins, like NaN and +inf
+  return (oc < bc && oc > -(T)INFINITY) || (oc == bc && oi >= 0 && oi < bi);
 }
 
 template <typename T, int ROWS>
@@ -568,7 +569,7 @@ __global__ __launch_bounds__(256) void k_lut_fallback(const T* __restrict__ lut,
             c = c + d * d;
           }
         }
-        if (c < bc) {                                  // ascending rows + strict '<': ties to the lowest row
+        if (c < bc && c > -(T)INFINITY) {              // ascending rows + strict '<': ties to the lowest row; -inf is not finite
           bc = c;
           bi = rb + rr;
         }

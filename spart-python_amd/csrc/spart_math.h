@@ -279,7 +279,9 @@ template <> struct Mx<double> {
   // square root: v_rsq_f64 (4.6e-8 relative) refined by ONE Newton step, sqrt x = g (1 + e/2 + O(e^2)), g = x y0,
   // e = 1 - g y0: relative error 3 e^2 / 8 < 1e-15 in 5 instructions (the library's sequence: ~14).  The argument of the
   // rsq is kept away from 0 by ADDING 1e-300 (x = 0 -> 0 * rsq(1e-300) = 0 instead of 0 * inf; x + 1e-300 == x for every
-  // normal x): a negative x gives NaN like np.sqrt (a max() here returned finite garbage), a NaN x stays NaN.
+  // normal x): a negative x <= -1e-300 gives NaN like np.sqrt (a max() here returned finite garbage), a NaN x
+  // stays NaN.  Outside that: -1e-300 < x < 0 returns a tiny negative finite value (|result| < 1e-150) instead of NaN, and a
+  // positive x below 1e-300 returns x * 1e150 (too small); no quantity of the model comes near either range.
   static SPART_HD double sqrt(double x) {
 #if defined(__HIP_DEVICE_COMPILE__) && defined(SPART_FAST_MATH)
     const double y0 = __builtin_amdgcn_rsq(x + 1e-300);

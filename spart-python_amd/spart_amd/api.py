@@ -86,10 +86,10 @@ def calculate_tav(alpha, nr):
 
 
 def PROSPECT_5D(leafbio, optical_params=None, dtype="float64", device=None):
-    """prospect_5d.py:117-246.  ``optical_params`` is accepted for signature compatibility; the
-    engine holds its own device copy of the same tables."""
+    """prospect_5d.py:117-246.  The nine spectral tables are read from ``optical_params`` as the reference reads them
+    (prospect_5d.py:158-167; None = load_optical_parameters()): the device context is chosen by their content."""
     _pro_warning(leafbio)
-    eng = _engine.get_engine(None, device)
+    eng = _engine.get_engine(None, device, optical_params=optical_params, need=_engine.LEAF_KEYS)
     refl, tran, kchl = eng.prospect(leafbio.columns(), dtype)
     sc = _is_scalar(*leafbio.columns())
     return LeafOptics(_colvec(refl, sc), _colvec(tran, sc), _colvec(kchl, sc))
@@ -203,21 +203,23 @@ class SoilParametersFromFile:
 
 
 def soilwat(rdry, nw, kw, SMp, SMC, deleff, dtype="float64", device=None):
-    """bsm.py:62-128: wet soil reflectance from a dry spectrum.  The water tables live in the device context
-    (model_parameters/optical_params): ``nw`` / ``kw`` must be those tables (they are checked, not used), anything else
-    is a ValueError rather than a silently different answer.  Returns the shape of ``rdry``."""
-    op = _tables.load_optical_parameters()
-    for given, name in ((nw, "nw"), (kw, "Kw")):
-        if given is not None and not np.array_equal(np.asarray(given, dtype=np.float64).reshape(-1), op[name].reshape(-1)):
-            raise ValueError(f"soilwat: {name} differs from the water table of the device context (load_optical_parameters())")
-    eng = _engine.get_engine(None, device)
+    """bsm.py:62-128: wet soil reflectance from a dry spectrum with the water tables ``nw`` / ``kw`` GIVEN (None = the
+    packaged ones): a device context holding exactly those two tables evaluates it.  Returns the shape of ``rdry``."""
+    op = {}
+    if nw is not None:
+        op["nw"] = nw
+    if kw is not None:
+        op["Kw"] = kw
+    eng = _engine.get_engine(None, device, optical_params=op or None, need=tuple(op))
     refl, _ = eng.bsm([None, None, None, SMp, SMC, deleff], dtype, rdry=rdry)
     return refl.cpu().numpy().reshape(np.shape(rdry)) if np.size(rdry) == 2001 else refl.cpu().numpy()
 
 
 def BSM(soilpar, optical_params=None, dtype="float64", device=None):
-    """bsm.py:17-59"""
-    eng = _engine.get_engine(None, device)
+    """bsm.py:17-59.  ``optical_params``: GSV, Kw and nw are read from it as the reference reads them (bsm.py:45, 54-55;
+    GSV only without a user dry spectrum, bsm.py:42-45); None = load_optical_parameters()."""
+    need = ("Kw", "nw") if soilpar.rdry_set else _engine.SOIL_KEYS
+    eng = _engine.get_engine(None, device, optical_params=optical_params, need=need)
     rdry = soilpar.rdry if soilpar.rdry_set else None
     refl, dry = eng.bsm(soilpar.columns(), dtype, rdry=rdry)
     sc = _is_scalar(*[c for c in soilpar.columns() if c is not None]) and (rdry is None or np.size(rdry) == 2001)
@@ -348,24 +350,13 @@ def SMAC(angles, atm, coefs, device=None):
 
 
 def _engine_for_coefs(coefs, device):
-    """One engine per (coefficient CONTENT, device): the reference's calling convention is
-    SMAC(angles, atm, sensorinfo['SMAC_coef']) with a freshly loaded dict each time, so the dict's identity says
-    nothing (CPython reuses the address of the previous, freed dict); the key is a digest of the stacked 48 x nb
-    float64 coefficient block."""
-    import hashlib
-    import torch
-    dev = int(torch.cuda.current_device() if device is None else device)
-    block = np.ascontiguousarray(np.stack([np.asarray(coefs[n], dtype=np.float64).reshape(-1) for n in _tables.COEF_NAMES]))
-    key = (hashlib.sha1(block.tobytes()).hexdigest(), block.shape[1], dev)
-    cache = _engine_for_coefs.__dict__.setdefault("cache", {})
-    if key not in cache:
-        if len(cache) >= 16:                      # a handful of sensors at most: do not hold device tables forever
-            cache.pop(next(iter(cache)))
-        nb = block.shape[1]
-        si = {"wl_smac": np.full((nb, 1), 500.0), "band_id_smac": [""] * nb, "SMAC_coef": coefs,
-              "wl_srf_smac": np.full((1, nb), 500.0), "p_srf_smac": np.ones((1, nb))}
-        cache[key] = _engine.Engine(None, dev, sensor_info=si)
-    return cache[key]
+    """The engine for a SMAC_coef dict: the reference's calling convention is SMAC(angles, atm, sensorinfo['SMAC_coef']) with a
+    freshly loaded dict each time, so the dict's identity says nothing; the engine is found by the CONTENT of the 48 x nb
+    coefficient block (engine.get_engine: content-keyed).  SMAC needs no band centres or response functions: placeholders."""
+    nb = int(np.size(coefs[_tables.COEF_NAMES[0]]))
+    si = {"wl_smac": np.full((nb, 1), 500.0), "band_id_smac": [""] * nb, "SMAC_coef": coefs,
+          "wl_srf_smac": np.full((1, nb), 500.0), "p_srf_smac": np.ones((1, nb))}
+    return _engine.get_engine(None, device, sensor_info=si)
 
 
 # ------------------------------------------------------------------------------- orchestration
@@ -462,11 +453,15 @@ class SPART:
         self.canopy = canopy
         self.atm = atm
         self.angles = angles
-        self.sensor = sensor                             # (property: loads sensorinfo; FileNotFoundError for unknown sensors, SPART.py:421-423)
         self.DOY = DOY
         self.dtype = dtype
         self.device = device
         self.spectral = SpectralBands()
+        # SPART.py:93-95: public, mutable, and READ BY run() -- an edit of any of the three dicts (or of an array inside
+        # one) changes the next run(), exactly as in the reference
+        self.optipar = load_optical_parameters()
+        self.ETpar = load_ET_parameters()
+        self.sensor = sensor                             # (property: loads sensorinfo; FileNotFoundError for unknown sensors, SPART.py:421-423)
 
     @property
     def sensor(self):
@@ -497,7 +492,10 @@ class SPART:
         eagerly in the same call instead."""
         import pandas as pd
         _pro_warning(self.leafbio)
-        eng = _engine.get_engine(self.sensor, self.device)
+        # the device context whose tables have the CONTENT of self.optipar / self.ETpar / self.sensorinfo right now
+        # (SPART.py:181-184, 192, 202, 216, 228); the unmodified dicts resolve to the packaged sensor's engine
+        eng = _engine.get_engine(self.sensor, self.device, optical_params=self.optipar, et_params=self.ETpar,
+                                 sensor_info=self.sensorinfo)
         cols = self._columns()
         fields = ["La"]
         if debug:

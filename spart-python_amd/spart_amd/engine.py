@@ -34,17 +34,108 @@ def _dp(a):
 ROW_PITCH = (2176, 2048)
 
 
+# ---- the static tables a context is built from (spart_tables): the reference reads them from the dicts it is HANDED at call
+# time -- PROSPECT_5D(leafbio, optical_params) prospect_5d.py:158-167, BSM(soilpar, optical_params) bsm.py:45, 54-55,
+# SPART.run() self.optipar / self.ETpar / self.sensorinfo SPART.py:93-95, 181-184, 192, 202, 228 -- so an engine is keyed on
+# their CONTENT, never on a name or on the identity of a dict.
+LEAF_KEYS = ("nr", "Kdm", "Kab", "Kca", "Kw", "Ks", "Kant", "cbc", "prot")       # prospect_5d.py:158-167
+SOIL_KEYS = ("GSV", "Kw", "nw")                                                     # bsm.py:45, 54-55
+OPTICAL_KEYS = ("nr", "Kab", "Kca", "Kdm", "Kw", "Ks", "Kant", "cbc", "prot", "GSV", "nw")
+SENSOR_KEYS = ("wl_smac", "SMAC_coef", "wl_srf_smac", "p_srf_smac")               # SPART.py:216, 228, 376-377
+
+try:                                         # (the digest is a cache key, not a security boundary)
+    import xxhash as _xx
+
+    def _hasher():
+        return _xx.xxh3_128()
+except ImportError:                          # pragma: no cover
+    import hashlib as _hl
+
+    def _hasher():
+        return _hl.sha1()
+
+
+def _digest(arrays):
+    h = _hasher()
+    for a in arrays:
+        h.update(np.asarray(a.shape, dtype=np.int64).tobytes())
+        h.update(a.data)
+    return h.hexdigest()
+
+
+def optical_block(optical_params=None, et_params=None, need=OPTICAL_KEYS):
+    """The twelve float64 host tables of spart_tables from the reference's dicts.  ``optical_params`` /
+    ``et_params`` = None means the packaged tables (load_optical_parameters / load_ET_parameters).  A key of ``need`` that
+    the dict lacks is the reference's own KeyError; keys the calling entry point never reads fall back to the packaged
+    table.  Anything that is not a 2001-point spectrum (GSV: (2001, 3)) -- or an ET wavelength axis that is not the
+    400..2400 nm grid the SRF convolution indexes -- is refused with a ValueError: never a silently different answer."""
+    z = tables._npz()
+    out = {}
+    for k in OPTICAL_KEYS:
+        if optical_params is None or (k not in optical_params and k not in need):
+            v = z[k]
+        else:
+            v = optical_params[k]            # KeyError like the reference's optical_params["..."]
+        a = np.ascontiguousarray(np.asarray(v, dtype=np.float64))
+        if k == "GSV":
+            if a.shape != (_lib.NWL, 3):
+                raise ValueError(f"optical_params['GSV'] has shape {a.shape}, expected ({_lib.NWL}, 3) (bsm.py:45-52)")
+        else:
+            if a.size != _lib.NWL:
+                raise ValueError(f"optical_params[{k!r}] has {a.size} entries, expected the {_lib.NWL} bands 400..2400 nm")
+            a = a.reshape(-1)
+        out[k] = a
+    if et_params is None:
+        out["Ea"] = np.ascontiguousarray(z["Ea"], dtype=np.float64)
+    else:
+        ea = np.ascontiguousarray(np.asarray(et_params["Ea"], dtype=np.float64)).reshape(-1)
+        if ea.size != _lib.NWL:
+            raise ValueError(f"ETpar['Ea'] has {ea.size} entries, expected {_lib.NWL}")
+        wl = np.asarray(et_params["wl_Ea"], dtype=np.float64).reshape(-1) if "wl_Ea" in et_params else None
+        if wl is None:
+            raise KeyError("wl_Ea")          # SPART.py:184
+        if wl.size != _lib.NWL or not np.array_equal(wl, np.arange(400, 2401, dtype=np.float64)):
+            raise ValueError("ETpar['wl_Ea'] must be the 1 nm grid 400..2400 nm: the SRF convolution of the device context "
+                             "(SPART.py:381-387) indexes that grid")
+        out["Ea"] = ea
+    return out
+
+
+def sensor_block(sensor_info):
+    """The sensor part of spart_tables from a sensorinfo dict (SPART.py:419-424): float64, validated shapes."""
+    for k in SENSOR_KEYS:
+        if k not in sensor_info:
+            raise KeyError(k)
+    wl = np.ascontiguousarray(np.asarray(sensor_info["wl_smac"], dtype=np.float64).reshape(-1))
+    nb = wl.shape[0]
+    coefs = sensor_info["SMAC_coef"]
+    rows = []
+    for n in tables.COEF_NAMES:
+        r = np.asarray(coefs[n], dtype=np.float64).reshape(-1)       # KeyError like smac.py:44-92
+        if r.size != nb:
+            raise ValueError(f"SMAC_coef[{n!r}] has {r.size} entries for {nb} sensor bands")
+        rows.append(r)
+    coef = np.ascontiguousarray(np.stack(rows))
+    wsrf = np.ascontiguousarray(np.asarray(sensor_info["wl_srf_smac"], dtype=np.float64))
+    psrf = np.ascontiguousarray(np.asarray(sensor_info["p_srf_smac"], dtype=np.float64))
+    if wsrf.ndim != 2 or wsrf.shape[1] != nb or psrf.shape != wsrf.shape:
+        raise ValueError(f"wl_srf_smac {wsrf.shape} / p_srf_smac {psrf.shape} must both be (nsrf, {nb})")
+    return dict(wl=wl, coef=coef, wsrf=wsrf, psrf=psrf)
+
+
+
 class Engine:
-    def __init__(self, sensor=None, device=0, sensor_info=None, lib_path=None, row_pitch=ROW_PITCH):
-        """row_pitch: (pitch of 2162-wide rows, pitch of 2001-wide rows) or None for dense arrays."""
+    def __init__(self, sensor=None, device=0, sensor_info=None, lib_path=None, row_pitch=ROW_PITCH, optical_params=None,
+                 et_params=None, need=OPTICAL_KEYS):
+        """sensor: a packaged sensor name, or None with ``sensor_info`` = a sensorinfo dict (both None: no sensor).
+        optical_params / et_params: the reference's table dicts (None = packaged); the context is built from THEIR content.
+        row_pitch: (pitch of 2162-wide rows, pitch of 2001-wide rows) or None for dense arrays."""
         torch = _require_gpu()
         self.lib = _lib.load(lib_path)
         self.torch = torch
         self.device = torch.device("cuda", device)
         self.sensor = sensor
-        z = tables._npz()
-        keep = {k: np.ascontiguousarray(z[k], dtype=np.float64)
-                for k in ("nr", "Kab", "Kca", "Kdm", "Kw", "Ks", "Kant", "cbc", "prot", "GSV", "nw", "Ea")}
+        keep = optical_block(optical_params, et_params, need)
         t = _lib.SpartTables()
         for k, v in keep.items():
             setattr(t, k, _dp(v))
@@ -52,17 +143,14 @@ class Engine:
         if sensor is not None or sensor_info is not None:
             si = sensor_info if sensor_info is not None else tables.load_sensor_info(sensor)
             self.sensor_info = si
-            wl = np.ascontiguousarray(np.asarray(si["wl_smac"], dtype=np.float64).reshape(-1))
-            coef = np.ascontiguousarray(np.stack([np.asarray(si["SMAC_coef"][n], dtype=np.float64).reshape(-1)
-                                                  for n in tables.COEF_NAMES]))
-            wsrf = np.ascontiguousarray(si["wl_srf_smac"], dtype=np.float64)
-            psrf = np.ascontiguousarray(si["p_srf_smac"], dtype=np.float64)
-            keep.update(wl=wl, coef=coef, wsrf=wsrf, psrf=psrf)
+            sb = sensor_block(si)
+            keep.update(sb)
+            wl, coef, wsrf, psrf = sb["wl"], sb["coef"], sb["wsrf"], sb["psrf"]
             t.nb, t.wl_smac, t.coef = wl.shape[0], _dp(wl), _dp(coef)
             t.nsrf, t.wl_srf, t.p_srf = wsrf.shape[0], _dp(wsrf), _dp(psrf)
             self.nb = int(wl.shape[0])
             self.wl_smac = np.asarray(si["wl_smac"]).reshape(-1)
-            self.band_id = list(si["band_id_smac"])
+            self.band_id = list(si["band_id_smac"]) if "band_id_smac" in si else [""] * self.nb
         self._keep = keep
         ctx = _lib.vp()
         rc = self.lib.spart_ctx_create(ctypes.byref(ctx), device, ctypes.byref(t))
@@ -417,14 +505,61 @@ class Engine:
         return out
 
 
-_engines = {}
+_engines = {}            # (sensor name, device) -> Engine built from the packaged tables: no hashing on this path
+_by_content = {}         # (table digest, sensor digest | None, device) -> Engine, least recently used last out
+_packaged_digest = {}    # memo: digests of the packaged tables ("optical") and sensors (name)
+MAX_CONTENT_ENGINES = 16  # a context is ~0.6 MB of device tables; a handful of table sets at most is expected
 
 
-def get_engine(sensor=None, device=None):
+def get_engine(sensor=None, device=None, optical_params=None, et_params=None, sensor_info=None, need=OPTICAL_KEYS):
+    """The engine (device context) for a sensor and a set of tables.
+
+    get_engine(sensor, device): the packaged tables and the packaged sensor ``sensor`` (or no sensor), one engine per
+    (name, device), found without looking at any table.
+    With ``optical_params`` / ``et_params`` / ``sensor_info`` (the reference's dicts: SPART.optipar, SPART.ETpar,
+    SPART.sensorinfo; PROSPECT_5D's and BSM's second argument): the engine whose device tables have exactly THAT content
+    -- the key is a digest of the arrays, re-computed on every call (~20 us with xxhash, 0.2 ms with sha1), so editing
+    a dict or one of its arrays in place between two calls gives the second call the edited tables, as in the
+    reference, and handing in the unmodified packaged dicts gives the very engine of the name-keyed path.
+    ``need``: the keys of optical_params the calling entry point reads (see optical_block)."""
     torch = _require_gpu()
     if device is None:
         device = torch.cuda.current_device()
-    key = (sensor, int(device))
-    if key not in _engines:
-        _engines[key] = Engine(sensor, int(device))
-    return _engines[key]
+    device = int(device)
+    if optical_params is None and et_params is None and sensor_info is None:
+        key = (sensor, device)
+        if key not in _engines:
+            _engines[key] = Engine(sensor, device)
+        return _engines[key]
+    if "optical" not in _packaged_digest:
+        _packaged_digest["optical"] = _digest(optical_block().values())
+    ob = optical_block(optical_params, et_params, need)
+    dt = _digest(ob.values())
+    ds = None
+    if sensor_info is not None:
+        ds = _digest(sensor_block(sensor_info).values())
+    elif sensor is not None:
+        ds = _packaged_digest.get(sensor)
+        if ds is None:
+            ds = _packaged_digest[sensor] = _digest(sensor_block(tables.load_sensor_info(sensor)).values())
+    # the packaged content under whatever dict it arrives in IS the name-keyed engine
+    if dt == _packaged_digest["optical"]:
+        if ds is None:
+            return get_engine(None, device)
+        for name in ([sensor] if isinstance(sensor, str) else []) + list(tables.SENSORS):
+            if name not in _packaged_digest:
+                try:
+                    _packaged_digest[name] = _digest(sensor_block(tables.load_sensor_info(name)).values())
+                except FileNotFoundError:
+                    continue
+            if _packaged_digest[name] == ds:
+                return get_engine(name, device)
+    key = (dt, ds, device)
+    eng = _by_content.pop(key, None)
+    if eng is None:
+        while len(_by_content) >= MAX_CONTENT_ENGINES:
+            _by_content.pop(next(iter(_by_content)))
+        eng = Engine(sensor if sensor_info is None else None, device, sensor_info=sensor_info, optical_params=optical_params,
+                     et_params=et_params, need=need)
+    _by_content[key] = eng                    # (re-inserted at the end: most recently used)
+    return eng

@@ -51,8 +51,7 @@ def load_sensor_info(sensor):
     if f"{sensor}/wl_smac" not in z:
         raise FileNotFoundError(f"[Errno 2] No such file or directory: 'sensor_information/{sensor}.pkl'")
     wl = z[f"{sensor}/wl_smac"]
-    if bool(z[f"{sensor}/wl_smac_is_int"]):
-        wl = wl.astype(np.uint16)
+    wl = wl.astype(np.uint16) if bool(z[f"{sensor}/wl_smac_is_int"]) else wl.copy()     # (a private copy either way)
     coef = z[f"{sensor}/coef"]
     return {
         "wl_smac": wl[:, None],

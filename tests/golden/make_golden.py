@@ -25,6 +25,10 @@ Files
                  comparison with smac.npz / e2e.npz / edge.npz has to allow for): the 12 SMAC rows of smac.npz, defaults,
                  PRO, the 256 config-4 rows, the 64 config-5 rows and the 128 edge rows.  Pins the ALGEBRA of smac_band on
                  the headline sensors at 1e-12 / 1e-10 (SPART.py:228, smac.py:44-92, 100-211)
+  tables.npz     the TABLE arguments honoured at call time (table_edits.py): PROSPECT_5D(lb, op') / BSM(sp, op') / soilwat with
+                 edited optical_params, and SPART objects whose optipar / ETpar / sensorinfo were edited between
+                 construction and run() (SPART.py:93-95 read at :181-184, 192, 202, 216, 228; prospect_5d.py:158-167;
+                 bsm.py:45, 54-55): defaults + 8 LHS rows per edit, Sentinel2A (+ MODIS for the sensorinfo edit)
   edge.npz       128 rows of tools/edge_sweep.py's widened ranges with edge values (LAI 0 / 1e-4 / 10, dry soil, N = 1,
                  zero pigments, exact hot spot, grazing angles, PRO leaves), Sentinel2A: P + R_TOC / R_TOA / L_TOA
 """
@@ -40,6 +44,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.normpath(os.path.join(HERE, "..", ".."))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, HERE)
 from _ref_import import import_reference  # noqa: E402
 
 SPART = import_reference()
@@ -262,6 +267,72 @@ def gen_s2f64():
     np.savez_compressed(os.path.join(HERE, "s2_f64.npz"), **out)
 
 
+def run_row_edited(args):
+    """run_row on an object edited between construction and run() (table_edits.OBJECT_EDITS)"""
+    import table_edits
+    row, sensor, edit = args
+    leaf, soil, can, ang, atm, doy = row[0:9], row[9:15], row[15:19], row[19:22], row[22:26], row[26]
+    with redirect_stdout(io.StringIO()):
+        sp = SPART.SPART(SoilParameters(*soil), LeafBiology(*leaf[:7], PROT=leaf[7], CBC=leaf[8]),
+                         CanopyStructure(*can), AtmosphericProperties(atm[0], atm[1], atm[2], Pa=atm[3]),
+                         Angles(*ang), sensor, int(doy))
+        table_edits.OBJECT_EDITS[edit](sp)
+        df = sp.run(debug=True)
+    return (df["R_TOC"].to_numpy(), df["R_TOA"].to_numpy(), df["L_TOA"].to_numpy(), df["rsoil"].to_numpy(),
+            np.asarray(sp._La, dtype=np.float64), np.asarray(df.index, dtype=np.float64), np.array(list(df["Band"]), dtype=str))
+
+
+def gen_tables():
+    """The table arguments the reference honours at call time, through the reference's own calls."""
+    import warnings
+    import table_edits
+    from SPART.bsm import soilwat
+    warnings.filterwarnings("ignore")
+    out = {}
+    op = SPART.load_optical_parameters()
+    leaf = np.array([[40, 0.01, 0.02, 0, 10, 10, 1.5, 0, 0], [25, 0.004, 0.012, 0.2, 6, 3, 2.2, 0, 0],
+                     [60, 0.0, 0.03, 0.0, 15, 1, 1.2, 0.0015, 0.006], [10, 0.02, 0.05, 0.5, 2, 0, 3.0, 0, 0]], dtype=np.float64)
+    for tag, opx in (("leaf", table_edits.optical_leaf(op)), ("leaf_keys_only", table_edits.optical_leaf_keys_only(op))):
+        res = {k: [] for k in ("refl", "tran", "kChlrel")}
+        for r in leaf:
+            with redirect_stdout(io.StringIO()):
+                lo = PROSPECT_5D(LeafBiology(*r[:7], PROT=r[7], CBC=r[8]), opx)
+            for k in res:
+                res[k].append(getattr(lo, k)[:, 0])
+        for k, v in res.items():
+            out[f"prospect/{tag}/{k}"] = np.array(v)
+    assert np.array_equal(out["prospect/leaf/refl"], out["prospect/leaf_keys_only/refl"])
+    out["prospect/P"] = leaf
+    soil = np.array([[0.5, 0, 100, 20, 25, 0.015], [0.9, 30, 120, 55, 25, 0.015], [0.3, -30, 80, 4, 25, 0.015],
+                     [0.7, 10, 90, 40, 30, 0.02]], dtype=np.float64)
+    ops = table_edits.optical_soil(op)
+    refl, dry = [], []
+    for r in soil:
+        so = BSM(SoilParameters(*r), ops)
+        refl.append(so.refl[:, 0]); dry.append(so.refl_dry[:, 0])
+    out["bsm/P"] = soil; out["bsm/refl"] = np.array(refl); out["bsm/refl_dry"] = np.array(dry)
+    wl = np.arange(400, 2401, dtype=np.float64)
+    rdry = (0.08 + 0.25 * (wl - 400) / 2000 + 0.02 * np.sin(wl / 90.0))[:, None]
+    sw = soilwat(rdry, ops["nw"], ops["Kw"], 30.0, 25.0, 0.015)
+    out["soilwat/rdry"] = rdry[:, 0]; out["soilwat/refl"] = np.asarray(sw.refl)[:, 0]
+    # SPART objects edited between construction and run()
+    d = workloads.default_row()
+    P = np.concatenate([d, workloads.lhs_params(8, "full", seed=23)])
+    groups = [(e, "Sentinel2A-MSI") for e in ("optipar", "inplace", "etpar", "sensorinfo", "upcast")] + [("sensorinfo", "TerraAqua-MODIS")]
+    with np.errstate(all="ignore"), Pool(8) as pool:
+        for edit, sensor in groups:
+            res = pool.map(run_row_edited, [(r, sensor, edit) for r in P], chunksize=2)
+            name = f"run/{edit}/{sensor}"
+            out[name + "/P"] = P
+            for j, k in enumerate(["R_TOC", "R_TOA", "L_TOA", "rsoil", "La"]):
+                out[f"{name}/{k}"] = np.array([r[j] for r in res])
+            out[name + "/index"] = res[0][5]; out[name + "/Band"] = res[0][6]
+            base = np.array([r[1] for r in pool.map(run_row_edited, [(r, sensor, "upcast") for r in P[:2]])])
+            dev = np.nanmax(np.abs(out[name + "/R_TOA"][:2] - base) / np.maximum(np.abs(base), 1e-6))
+            print(name, P.shape, "R_TOA moved by up to %.2e against the unedited object" % dev, flush=True)
+    np.savez_compressed(os.path.join(HERE, "tables.npz"), **out)
+
+
 def gen_rdry():
     """Full chain with user dry-soil spectra (SoilParametersFromFile with an array, bsm.py:155-199, 42-43)."""
     from SPART.bsm import SoilParametersFromFile
@@ -416,6 +487,6 @@ def gen_grids():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["prospect", "bsm", "sailh", "smac", "e2e", "rdry", "jpl", "edge", "s2f64"]
+    which = sys.argv[1:] or ["prospect", "bsm", "sailh", "smac", "e2e", "rdry", "jpl", "edge", "s2f64", "tables"]
     for w in which:
         globals()["gen_" + w]()

@@ -1,0 +1,261 @@
+"""The TABLE arguments the reference honours at call time (VERDICT r4 "Missing 1"): PROSPECT_5D(leafbio, optical_params)
+prospect_5d.py:158-167, BSM(soilpar, optical_params) bsm.py:45, 54-55, soilwat(rdry, nw, kw, ...) bsm.py:62, and the public
+SPART attributes optipar / ETpar / sensorinfo that run() reads every time (SPART.py:93-95 -> :181-184, 192, 202, 216, 228).
+
+tests/golden/tables.npz holds the REFERENCE's answers for the edits of tests/golden/table_edits.py.  CPU: the oracle with
+the edited tables reproduces them (so the oracle is pinned on this axis too).  GPU: this package's public API, handed the
+same edited dicts, reproduces them -- no entry point accepts a table and ignores it.
+"""
+import io
+import os
+import sys
+import warnings
+from contextlib import redirect_stdout
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, rel_err
+
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import table_edits  # noqa: E402
+
+GROUPS = [("optipar", "Sentinel2A-MSI"), ("inplace", "Sentinel2A-MSI"), ("etpar", "Sentinel2A-MSI"),
+          ("sensorinfo", "Sentinel2A-MSI"), ("upcast", "Sentinel2A-MSI"), ("sensorinfo", "TerraAqua-MODIS")]
+
+
+@pytest.fixture(scope="module")
+def fx():
+    return np.load(os.path.join(ROOT, "tests", "golden", "tables.npz"))
+
+
+class _Holder:
+    """what table_edits.OBJECT_EDITS edits: optipar / ETpar / sensorinfo, here from this package's loaders (no GPU needed)"""
+
+    def __init__(self, sensor):
+        from spart_amd import tables as T
+        self.optipar, self.ETpar, self.sensorinfo = T.load_optical_parameters(), T.load_ET_parameters(), T.load_sensor_info(sensor)
+
+
+def _oracle_tables(h, sensor):
+    """the oracle's flat table dict from the three reference-style dicts"""
+    from spart_amd import tables as T
+    t = {k: np.asarray(h.optipar[k], dtype=np.float64).reshape(-1) for k in ("nr", "Kab", "Kca", "Kdm", "Kw", "Ks", "Kant", "cbc", "prot", "nw")}
+    t["GSV"] = np.asarray(h.optipar["GSV"], dtype=np.float64)
+    t["Ea"] = np.asarray(h.ETpar["Ea"], dtype=np.float64).reshape(-1)
+    si = h.sensorinfo
+    t[sensor + "/wl_smac"] = np.asarray(si["wl_smac"], dtype=np.float64).reshape(-1)
+    t[sensor + "/coef"] = np.stack([np.asarray(si["SMAC_coef"][n], dtype=np.float64).reshape(-1) for n in T.COEF_NAMES])
+    t[sensor + "/wl_srf"] = np.asarray(si["wl_srf_smac"], dtype=np.float64)
+    t[sensor + "/p_srf"] = np.asarray(si["p_srf_smac"], dtype=np.float64)
+    return t
+
+
+# ------------------------------------------------------------------------------------------------ CPU: the oracle
+def test_fixture_edits_move_the_reference(fx):
+    """the fixtures are worth something: each edit moved the reference's answer (or, for Ea, exactly halved L_TOA)"""
+    base = fx["run/upcast/Sentinel2A-MSI/R_TOA"]
+    for e in ("optipar", "inplace", "sensorinfo"):
+        assert rel_err(fx[f"run/{e}/Sentinel2A-MSI/R_TOA"], base) > 1e-2
+    assert np.array_equal(fx["run/etpar/Sentinel2A-MSI/R_TOA"], base)
+    assert rel_err(fx["run/etpar/Sentinel2A-MSI/L_TOA"], 0.5 * fx["run/upcast/Sentinel2A-MSI/L_TOA"], 1e-12) < 1e-14
+    assert np.array_equal(fx["prospect/leaf/refl"], fx["prospect/leaf_keys_only/refl"])
+    assert fx["run/sensorinfo/Sentinel2A-MSI/index"][0] == 445 + 3.5 and str(fx["run/sensorinfo/Sentinel2A-MSI/Band"][0]).startswith("x")
+
+
+def test_oracle_with_edited_optical_tables(oracle, fx):
+    h = _Holder("Sentinel2A-MSI")
+    t = _oracle_tables(h, "Sentinel2A-MSI")
+    tl = dict(t)
+    ol = table_edits.optical_leaf(h.optipar)
+    for k in ("Kab", "nr", "prot"):
+        tl[k] = np.asarray(ol[k]).reshape(-1)
+    refl, tran, kchl = oracle.prospect_5d(fx["prospect/P"], tl)
+    assert np.nanmax(np.abs(refl - fx["prospect/leaf/refl"])) < 5e-8       # (closed-form E1 vs QUADPACK, as in test_oracle_golden)
+    assert np.nanmax(np.abs(tran - fx["prospect/leaf/tran"])) < 5e-8
+    assert rel_err(kchl, fx["prospect/leaf/kChlrel"], 1e-12) < 1e-12
+    ts = dict(t)
+    os_ = table_edits.optical_soil(h.optipar)
+    ts["GSV"], ts["Kw"], ts["nw"] = os_["GSV"], np.asarray(os_["Kw"]).reshape(-1), np.asarray(os_["nw"]).reshape(-1)
+    wet, dry = oracle.bsm(fx["bsm/P"], ts)
+    assert rel_err(wet, fx["bsm/refl"], 1e-9) < 1e-12 and rel_err(dry, fx["bsm/refl_dry"], 1e-9) < 1e-12
+    wet, _ = oracle.bsm(np.array([[0, 0, 0, 30.0, 25.0, 0.015]]), ts, rdry=fx["soilwat/rdry"][None, :])
+    assert rel_err(wet[0], fx["soilwat/refl"], 1e-9) < 1e-12
+
+
+@pytest.mark.parametrize("edit,sensor", GROUPS)
+def test_oracle_with_edited_object_tables(oracle, fx, edit, sensor):
+    h = _Holder(sensor)
+    table_edits.OBJECT_EDITS[edit](h)
+    name = f"run/{edit}/{sensor}"
+    out = oracle.spart_run(fx[name + "/P"], sensor, tables=_oracle_tables(h, sensor), full=True)
+    for k in ("R_TOC", "R_TOA", "L_TOA", "rsoil", "La"):
+        assert rel_err(out[k], fx[f"{name}/{k}"]) < 2e-8, (edit, sensor, k)     # (E1 closed form vs QUADPACK: ~1e-8 on the columns)
+
+
+def test_engine_table_validation_needs_no_gpu():
+    """what is refused is refused on the host, before any device work"""
+    from spart_amd import engine as E, tables as T
+    op = T.load_optical_parameters()
+    blk = E.optical_block(op, T.load_ET_parameters())
+    assert set(blk) == set(E.OPTICAL_KEYS) | {"Ea"} and blk["GSV"].shape == (2001, 3) and blk["Kab"].shape == (2001,)
+    bad = dict(op)
+    bad["Kab"] = op["Kab"][:-1]
+    with pytest.raises(ValueError, match="Kab"):
+        E.optical_block(bad)
+    with pytest.raises(KeyError):
+        E.optical_block({k: v for k, v in op.items() if k != "Kab"}, need=E.LEAF_KEYS)
+    # a key the entry point never reads may be absent (the reference would not touch it either)
+    assert np.array_equal(E.optical_block({k: op[k] for k in E.LEAF_KEYS}, need=E.LEAF_KEYS)["GSV"], op["GSV"])
+    et = T.load_ET_parameters()
+    et["wl_Ea"] = et["wl_Ea"].astype(np.float64) + 0.5
+    with pytest.raises(ValueError, match="wl_Ea"):
+        E.optical_block(op, et)
+    si = T.load_sensor_info("Sentinel2A-MSI")
+    si["p_srf_smac"] = si["p_srf_smac"][:, :-1]
+    with pytest.raises(ValueError, match="p_srf_smac"):
+        E.sensor_block(si)
+    # loaders hand out private copies: an in-place edit of one dict never reaches the next load
+    a = T.load_sensor_info("TerraAqua-MODIS")
+    a["wl_smac"] += 1.0
+    a["SMAC_coef"]["taur"] *= 2
+    b = T.load_sensor_info("TerraAqua-MODIS")
+    assert np.array_equal(b["wl_smac"] + 1.0, a["wl_smac"]) and not np.array_equal(b["SMAC_coef"]["taur"], a["SMAC_coef"]["taur"])
+
+
+# ------------------------------------------------------------------------------------------------ GPU: the public API
+@pytest.fixture(scope="module")
+def SP():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    import SPART
+    return SPART
+
+
+@pytest.mark.gpu
+def test_prospect_reads_the_tables_it_is_given(SP, fx):
+    op = SP.load_optical_parameters()
+    for tag, opx in (("leaf", table_edits.optical_leaf(op)), ("leaf_keys_only", table_edits.optical_leaf_keys_only(op))):
+        for i, r in enumerate(fx["prospect/P"]):
+            with redirect_stdout(io.StringIO()):
+                lo = SP.PROSPECT_5D(SP.LeafBiology(*r[:7], PROT=r[7], CBC=r[8]), opx)
+            assert lo.refl.shape == (2001, 1)
+            # the bounds of test_prospect_golden / the reference's own assert_almost_equal precision (1.5e-7)
+            assert np.nanmax(np.abs(lo.refl[:, 0] - fx[f"prospect/{tag}/refl"][i])) < 1e-7
+            assert np.nanmax(np.abs(lo.tran[:, 0] - fx[f"prospect/{tag}/tran"][i])) < 1e-7
+            assert rel_err(lo.kChlrel[:, 0], fx[f"prospect/{tag}/kChlrel"][i], 1e-9) < 1e-9
+    # ... and the packaged tables still give the packaged answer afterwards (the edited context did not replace it)
+    r = fx["prospect/P"][0]
+    a = SP.PROSPECT_5D(SP.LeafBiology(*r[:7]), op).refl
+    b = SP.PROSPECT_5D(SP.LeafBiology(*r[:7])).refl
+    assert np.array_equal(a, b) and np.max(np.abs(a[:, 0] - fx["prospect/leaf/refl"][0])) > 1e-3
+    with pytest.raises(KeyError):
+        SP.PROSPECT_5D(SP.LeafBiology(*r[:7]), {k: v for k, v in op.items() if k != "Kant"})
+
+
+@pytest.mark.gpu
+def test_bsm_and_soilwat_read_the_tables_they_are_given(SP, fx):
+    op = SP.load_optical_parameters()
+    ops = table_edits.optical_soil(op)
+    for i, r in enumerate(fx["bsm/P"]):
+        so = SP.BSM(SP.SoilParameters(*r), ops)
+        assert rel_err(so.refl[:, 0], fx["bsm/refl"][i], 1e-9) < 1e-9
+        assert rel_err(so.refl_dry[:, 0], fx["bsm/refl_dry"][i], 1e-9) < 1e-9
+    from spart_amd.api import soilwat
+    rd = fx["soilwat/rdry"][:, None]
+    got = soilwat(rd, ops["nw"], ops["Kw"], 30.0, 25.0, 0.015)
+    assert got.shape == rd.shape and rel_err(got[:, 0], fx["soilwat/refl"], 1e-9) < 1e-9
+    # the packaged water tables, given explicitly or not, are another answer
+    base = soilwat(rd, op["nw"], op["Kw"], 30.0, 25.0, 0.015)
+    assert np.array_equal(base, soilwat(rd, None, None, 30.0, 25.0, 0.015)) and rel_err(base[:, 0], fx["soilwat/refl"]) > 1e-3
+    # a user dry spectrum makes GSV unnecessary (bsm.py:42-45): a dict without it is fine there, a KeyError otherwise
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        nog = {k: v for k, v in ops.items() if k != "GSV"}
+        so = SP.BSM(SP.SoilParametersFromFile(rd.copy(), 30.0, 25.0, 0.015), nog)
+        assert rel_err(so.refl[:, 0], fx["soilwat/refl"], 1e-9) < 1e-9
+        with pytest.raises(KeyError):
+            SP.BSM(SP.SoilParameters(0.5, 0, 100, 20, 25, 0.015), nog)
+
+
+def _object(SP, row, sensor, dtype="float64"):
+    leaf, soil, can, ang, atm, doy = row[0:9], row[9:15], row[15:19], row[19:22], row[22:26], row[26]
+    return SP.SPART(SP.SoilParameters(*soil), SP.LeafBiology(*leaf[:7], PROT=leaf[7], CBC=leaf[8]), SP.CanopyStructure(*can),
+                    SP.AtmosphericProperties(atm[0], atm[1], atm[2], Pa=atm[3]), SP.Angles(*ang), sensor, int(doy), dtype=dtype)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("edit,sensor", GROUPS)
+def test_run_reads_the_object_tables(SP, fx, edit, sensor):
+    """sp = SPART.SPART(...); <edit sp.optipar / sp.ETpar / sp.sensorinfo>; sp.run() -- row by row as the reference is used,
+    then the whole group as ONE batched object"""
+    name = f"run/{edit}/{sensor}"
+    P = fx[name + "/P"]
+    for i, row in enumerate(P[:3]):
+        sp = _object(SP, row, sensor)
+        before = sp.run()
+        table_edits.OBJECT_EDITS[edit](sp)
+        df = sp.run(debug=True)
+        for k in ("R_TOC", "R_TOA", "L_TOA", "rsoil"):
+            assert rel_err(df[k].to_numpy(), fx[f"{name}/{k}"][i]) < 1e-8, (edit, sensor, i, k)
+        assert rel_err(sp._La[0], fx[name + "/La"][i], 1e-12) < 1e-9
+        assert np.array_equal(np.asarray(df.index, dtype=np.float64), fx[name + "/index"])
+        assert list(df["Band"]) == [str(b) for b in fx[name + "/Band"]]
+        if edit not in ("upcast", "etpar"):
+            assert rel_err(before["R_TOA"].to_numpy(), fx[f"{name}/R_TOA"][i]) > 1e-3      # the edit is what moved it
+    cols = [P[:, j] for j in range(27)]
+    sp = SP.SPART(SP.SoilParameters(*cols[9:15]), SP.LeafBiology(*cols[0:7], PROT=cols[7], CBC=cols[8]), SP.CanopyStructure(*cols[15:19]),
+                  SP.AtmosphericProperties(cols[22], cols[23], cols[24], Pa=cols[25]), SP.Angles(*cols[19:22]), sensor, 100)
+    table_edits.OBJECT_EDITS[edit](sp)
+    with redirect_stdout(io.StringIO()):
+        res = sp.run()
+    for k in ("R_TOC", "R_TOA", "L_TOA"):
+        assert rel_err(res[k], fx[f"{name}/{k}"]) < 1e-8, (edit, sensor, k)
+    assert np.array_equal(np.asarray(res.wavelengths, dtype=np.float64), fx[name + "/index"])
+
+
+@pytest.mark.gpu
+def test_sentinel2_float64_fixture_through_the_public_api(SP, golden):
+    """tests/golden/s2_f64.npz -- made by up-casting sensorinfo['SMAC_coef'] on the reference OBJECT (make_golden.py
+    gen_s2f64) -- reproduced the same way: on this package's object, through run()"""
+    g = golden["s2_f64"]
+    for name in ("defaults/Sentinel2A-MSI", "pro/Sentinel2B-MSI", "lhs_full/Sentinel2A-MSI", "lhs_pro/Sentinel2B-MSI"):
+        sensor = name.split("/")[1]
+        P = g[name + "/P"][:64]
+        cols = [P[:, j] for j in range(27)]
+        sp = SP.SPART(SP.SoilParameters(*cols[9:15]), SP.LeafBiology(*cols[0:7], PROT=cols[7], CBC=cols[8]), SP.CanopyStructure(*cols[15:19]),
+                      SP.AtmosphericProperties(cols[22], cols[23], cols[24], Pa=cols[25]), SP.Angles(*cols[19:22]), sensor, 100)
+        assert all(np.asarray(v).dtype == np.float32 for v in sp.sensorinfo["SMAC_coef"].values())
+        with redirect_stdout(io.StringIO()):
+            r32 = sp.run()
+            sp.sensorinfo["SMAC_coef"] = {k: np.asarray(v).astype(np.float64) for k, v in sp.sensorinfo["SMAC_coef"].items()}
+            r64 = sp.run()
+        # identical VALUES (float32 -> float64 is exact): the same engine, bit-identical columns
+        for k in ("R_TOC", "R_TOA", "L_TOA"):
+            assert np.array_equal(np.atleast_2d(r32[k]), np.atleast_2d(r64[k]))
+            assert rel_err(np.atleast_2d(r64[k]), g[f"{name}/{k}"][:64]) < 1e-8, (name, k)
+
+
+@pytest.mark.gpu
+def test_content_keyed_engines_are_shared_and_bounded(SP):
+    from spart_amd import engine as E, get_engine
+    op, et = SP.load_optical_parameters(), SP.load_ET_parameters()
+    si = SP.load_sensor_info("Sentinel2A-MSI")
+    named = get_engine("Sentinel2A-MSI", 0)
+    # the packaged content, under whatever dicts it arrives in, is the name-keyed engine (no second context)
+    assert get_engine("Sentinel2A-MSI", 0, optical_params=op, et_params=et, sensor_info=si) is named
+    assert get_engine(None, 0, optical_params=op, need=E.LEAF_KEYS) is get_engine(None, 0)
+    # equal content in different dict / array objects -> one engine; different content -> another
+    a = get_engine(None, 0, optical_params=table_edits.optical_leaf(op))
+    b = get_engine(None, 0, optical_params=table_edits.optical_leaf(SP.load_optical_parameters()))
+    assert a is b and a is not get_engine(None, 0)
+    # an in-place edit of an array inside the SAME dict is seen by the next call
+    op["Kab"] *= 1.1
+    c = get_engine(None, 0, optical_params=op)
+    assert c is not get_engine(None, 0)
+    # the cache is bounded
+    for i in range(E.MAX_CONTENT_ENGINES + 3):
+        o = dict(op)
+        o["Kab"] = op["Kab"] * (1 + 0.01 * (i + 1))
+        get_engine(None, 0, optical_params=o)
+    assert len(E._by_content) <= E.MAX_CONTENT_ENGINES
