@@ -96,17 +96,17 @@ typedef struct spart_materialize {
                                   bsm.py:42-43, 155-199); params[9..11] (B, lat, lon) may then be NULL */
   void *band_mean;             /* (4,2162) batch means of rso, rdo, rsd, rdd (LUT summary; no reference counterpart) */
   int32_t prune_unused_bands;  /* R_TOC / R_TOA / L_TOA (and rsoil) ALWAYS come from the <= 2 nb spectral bands they depend on
-                                  (np.interp support points, SPART.py:220-223): prelude -> sensor-slot pass -> sensor kernel.
+                                  (np.interp support points, SPART.py:220-223): prelude -> column kernel.
                                   0 (default): beside that, every one of the 2162 bands of every sample is evaluated by the
                                   fused full-band kernel (band sums / band_mean / the spectra requested above); 1: that
                                   kernel only runs for requested spectra -- identical columns (the same kernels produce
                                   them), the work is not "full spectra" */
-  int32_t f32_columns;         /* dtype SPART_F32 only.  0 (default): the column path (prelude constants, sensor-slot bands,
-                                  SMAC, TOC->TOA) is float64 whatever the dtype, so R_TOC / R_TOA / L_TOA are the float64
+  int32_t f32_columns;         /* dtype SPART_F32 only.  0 (default): the column path (prelude constants, the canopy model at
+                                  the sensor bands, SMAC, TOC->TOA) is float64 whatever the dtype, so R_TOC / R_TOA / L_TOA are the float64
                                   mode's values rounded once to float32 (the 1e-4 contract then also holds for nearly
                                   conservative PROSPECT-PRO leaves, where the reference's canopy formulas cancel,
                                   sailh.py:185-214); materialised spectra and band_mean are float32 arithmetic.
-                                  1: the sensor-slot bands are evaluated in float32 as well (fast prelude) */
+                                  1: the canopy model at the sensor bands is evaluated in float32 as well (fast prelude) */
   int32_t f32_bands;           /* dtype SPART_F64 only.  1: R_TOC / R_TOA / L_TOA (and rsoil, La) are float64 and IDENTICAL
                                   to the float64 mode's -- they come from the same float64 column path -- while the
                                   evaluation of all 2162 bands of every sample (the band sums) runs in float32.
@@ -152,8 +152,8 @@ int spart_ctx_set_row_pitch(spart_ctx *ctx, int64_t pitch_full, int64_t pitch_op
  * Python mirror of the reference function runs the same arithmetic. */
 int spart_calculate_tav(double alpha_deg, const double *nr, int64_t n, double *out);
 
-/* Bytes of scratch the batched entry points need for B samples (prelude constants + the
- * canopy values at the sensor bands).  The same buffer may be reused by successive calls
+/* Bytes of scratch the batched entry points need for B samples (the prelude's per-sample constants, ~0.9 KB per
+ * sample, + the band sums of the full-band kernel).  The same buffer may be reused by successive calls
  * on one stream.  spart_smac_batch sizes its workspace with dtype = SPART_F64. */
 size_t spart_workspace_bytes(const spart_ctx *ctx, int dtype, int64_t B);
 
@@ -219,12 +219,12 @@ int spart_lut_stats(spart_ctx *ctx, int dtype, int64_t B, int nb, int64_t M, con
                     double *nmax);
 
 /* Measurement aid (bench.py): when enabled, spart_run_batch brackets each of its kernels with HIP events recorded on
- * the caller's stream, for up to max_calls calls (max_calls = 0 disables).  spart_profile_read_stages waits for them
- * and returns the summed milliseconds per stage -- [0] prelude (per-sample constants), [1] the fused full-band kernel
- * (PROSPECT + BSM + SAILH, the dominant one), [2] the float64 sensor-slot pass, [3] the sensor kernel (interpolation,
- * SMAC, TOC->TOA; includes the band-mean reduction when requested) -- and the number of timed calls;
- * spart_profile_read returns stage [1] only. */
-#define SPART_NSTAGE 4
+ * the stream the kernel runs on, for up to max_calls calls (max_calls = 0 disables).  spart_profile_read_stages waits for
+ * them and returns the summed milliseconds per stage -- [0] prelude (per-sample constants), [1] the fused full-band kernel
+ * (PROSPECT + BSM + SAILH over all 2162 bands, the dominant one; includes the band-mean reduction when requested),
+ * [2] the column kernel (canopy model at the sensor bands, interpolation, SMAC, TOC->TOA) -- and the number of timed
+ * calls; spart_profile_read returns stage [1] only. */
+#define SPART_NSTAGE 3
 int spart_profile_enable(spart_ctx *ctx, int max_calls);
 int spart_profile_read(spart_ctx *ctx, double *total_ms, int *ncalls);
 int spart_profile_read_stages(spart_ctx *ctx, double stage_ms[SPART_NSTAGE], int *ncalls);

@@ -40,11 +40,10 @@ struct spart_ctx {
   float* tabF = nullptr;    // (NTAB, NWL)
   double* tabD = nullptr;   // (NTAB, NWL)
   double* Ea = nullptr;     // (NWL)
-  int nb = 0, nslot = 0;
+  int nb = 0;
   int pf = NWLS, po = NWL;  // row pitch (elements) of the 2162- / 2001-wide spectrum arrays (spart_ctx_set_row_pitch)
-  int* slot_band = nullptr;  // (nslot) slot -> eval index (the bands the sensor-slot pass evaluates)
-  int* slot0 = nullptr;      // (nb)
-  int* slot1 = nullptr;      // (nb)
+  int* band0 = nullptr;      // (nb) evaluation index of the np.interp support point at / below the band centre (k_columns)
+  int* band1 = nullptr;      // (nb) ... of the next one (== band0 when the centre is a grid point)
   double* frac = nullptr;    // (nb)
   double* coef = nullptr;    // (48, nb)
   double* econv = nullptr;   // (nb)
@@ -53,7 +52,7 @@ struct spart_ctx {
   // and issues its launches (microseconds; the GPU work itself stays asynchronous), so calls on ONE context may come from
   // any number of host threads and streams.
   std::mutex mu;
-  // The column kernels (float64 slot pass + sensor kernel) run on a side stream beside the full-band kernel (fork / join
+  // The column kernel (k_columns) runs on a side stream beside the full-band kernel (fork / join
   // with two events; spart_run_batch stays asynchronous on the caller's stream).  One lane PER CALLER STREAM, created on
   // first use: two caller streams never share a side stream or an event pair, and a stream under HIP-graph capture
   // pulls only its own side stream into the capture.
@@ -67,10 +66,10 @@ struct spart_ctx {
   bool profile = false;
   std::vector<hipEvent_t> ev;   // NEV events per timed call (run_impl)
   size_t ev_used = 0;
-  std::vector<char> ev_forked;  // per timed call: slot pass + sensor kernel ran on the side stream
+  std::vector<char> ev_forked;  // per timed call: the column kernel ran on the side stream
 };
 
-constexpr size_t NEV = 5;        // events per timed spart_run_batch call: 4 stage intervals
+constexpr size_t NEV = 4;        // events per timed spart_run_batch call: 3 stage intervals
 
 // the text of the last error raised ON THE CALLING THREAD (spart_last_error): per thread, so that concurrent calls on one
 // context cannot garble each other's message
@@ -221,7 +220,7 @@ constexpr int64_t SPART_MAX_BATCH = 60000000;
 inline size_t align_up(size_t x) { return (x + 255) & ~size_t(255); }
 
 struct Workspace {
-  size_t cstf_off, cstd_off, atm_off, g_off, gs_off, bs_off, total;
+  size_t cstf_off, cstd_off, atm_off, bs_off, total;
   int64_t Bp;       // row pitch of the structure-of-arrays blocks (spart_kernels.h)
 };
 
@@ -245,19 +244,17 @@ int pick_chunk(int64_t B) {
   return (int)(c < 1 ? 1 : c);
 }
 
-Workspace carve(int dtype, int64_t B, int nslot) {
+Workspace carve(int dtype, int64_t B) {
   size_t es = dtype == SPART_F64 ? 8 : 4;
   Workspace w;
   w.Bp = row_pitch_of(B);
-  const size_t Bp = (size_t)w.Bp, ns = (size_t)(nslot > 0 ? nslot : 1);
+  const size_t Bp = (size_t)w.Bp;
   size_t o = 0;
-  // float32 constants only in the float32 modes; the float64 constants, the G rows and the rsoil slots are sized for
-  // float64 in both (the default float32 mode keeps them in float64: k_slots<double>)
+  // float32 constants only in the float32 modes; the float64 constants are there in both (the default float32 mode's
+  // column kernel is float64: k_columns<double, float>).  ~0.9 KB per sample.
   w.cstf_off = o; o = align_up(o + Bp * NCONST * 4);     // (float64 calls use it with spart_materialize.f32_bands)
   w.cstd_off = o; o = align_up(o + Bp * NCONST * 8);
   w.atm_off = o;  o = align_up(o + Bp * NATM * 8);
-  w.g_off = o;    o = align_up(o + Bp * ns * 4 * 8);
-  w.gs_off = o;   o = align_up(o + Bp * ns * 8);
   int chunk = pick_chunk(B);
   size_t nchunk = (size_t)((B + chunk - 1) / chunk);
   w.bs_off = o;  o = align_up(o + nchunk * (size_t)(NTILE * TILE) * 4 * es);
@@ -370,10 +367,10 @@ static int sailh_impl(spart_ctx* ctx, int64_t B, const void* rho, const void* ta
 }
 
 // T = dtype of the full-band kernel (band sums, materialised spectra); TG = dtype of the column path: the prelude's
-// constants, the sensor-slot pass, the G rows and rsoil slots (double, except spart_materialize.f32_columns); TO = dtype
+// constants and the canopy model inside the column kernel (double, except spart_materialize.f32_columns); TO = dtype
 // of the (B, nb) outputs.  <double,double,double> = float64 mode; <float,double,float> = the default float32 mode;
 // <float,double,double> = f32_bands; <float,float,float> = f32_columns.
-// In EVERY mode the columns come from prelude -> k_slots<TG> -> k_sensor, i.e. from the <= 2 nb bands they depend on; the
+// In EVERY mode the columns come from prelude -> k_columns<TG, TO>, i.e. from the <= 2 nb bands they depend on; the
 // full-band kernel runs beside that on the caller's stream whenever full spectra are asked for (opt = NULL: band sums).
 template <typename T, typename TG, typename TO = T>
 static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_NPARAM], const double* rho_th,
@@ -389,8 +386,6 @@ static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_
   const T* cst = sizeof(T) == 4 ? (const T*)cstF : (const T*)cstD;       // the full-band kernel's constants
   const TG* cstG = sizeof(TG) == 4 ? (const TG*)cstF : (const TG*)cstD;  // the slot pass's constants
   double* atm = (double*)(wsp + ws.atm_off);
-  TG* G = (TG*)(wsp + ws.g_off);
-  TG* gs = (TG*)(wsp + ws.gs_off);
   // ---- everything that can fail on its arguments is checked BEFORE any launch (and before the side stream is forked)
   int chunk = pick_chunk(B);
   int64_t nchunk = (B + chunk - 1) / chunk;
@@ -413,11 +408,12 @@ static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_
   if (opt && opt->band_mean && !full)
     return fail(ctx, SPART_ERR_INVALID, "spart_run_batch: band_mean needs prune_unused_bands = 0");
   const int narr = 3 + (want_rsoil ? 1 : 0) + ((opt && opt->La) ? 1 : 0);
-  const size_t lds = (size_t)narr * 64 * ctx->nb * sizeof(TO);     // <= 5 * 64 * 64 * 8 = 160 KiB only for nb = 64 fp64
+  // LDS staging of the results: only the (measurement) variant of k_columns that transposes through LDS
+  const size_t lds = SPART_COLUMNS_DIRECT ? 0 : (size_t)narr * 64 * ctx->nb * sizeof(TO);     // <= 5 * 64 * 64 * 8 = 160 KiB only for nb = 64 fp64
   if (lds > 64 * 1024) return fail(ctx, SPART_ERR_INVALID, "spart_run_batch: %d sensor bands need %zu B of LDS staging", ctx->nb, lds);
   int rc;
-  // optional per-stage timing: five events per call (before the prelude, after the prelude, the full-band kernel, the
-  // slot pass, the sensor kernel)
+  // optional per-stage timing: four events per call (before the prelude, after the prelude, after the full-band kernel,
+  // after the column kernel)
   const bool prof = ctx->profile && ctx->ev_used + NEV <= ctx->ev.size();
   hipEvent_t* ev = prof ? &ctx->ev[ctx->ev_used] : nullptr;
   if (prof) HIP_TRY(ctx, hipEventRecord(ev[0], st));
@@ -437,26 +433,19 @@ static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_
   dim3 grid(xcd_grid(nchunk));
   T* bsum = (T*)(wsp + ws.bs_off);
   if (prof) HIP_TRY(ctx, hipEventRecord(ev[1], st));
-  // The columns do not depend on the full-band kernel, so the slot pass + sensor kernel run on the context's side stream
-  // BESIDE it and fill issue slots it leaves idle; the caller's stream waits for them at the end.
+  // The columns do not depend on the full-band kernel, so the column kernel runs on the context's side stream BESIDE it
+  // and fills issue slots it leaves idle; the caller's stream waits for it at the end.
   SideLane* lane = bands ? lane_for(ctx, st) : nullptr;
   const bool fork = lane != nullptr;
   hipStream_t s2 = fork ? lane->side : st;
-  auto columns = [&]() -> int {                // slot pass + sensor kernel, on s2
-    hipLaunchKernelGGL((k_slots<TG, TO>), dim3((unsigned)((B + 63) / 64)), dim3(256), 0, s2, tabG,
-                       cstG, Bp, (const int*)ctx->slot_band, G, (TG*)(want_rsoil ? gs : nullptr),
-                       (const TO*)(opt ? opt->rdry_in : nullptr), ctx->po, B, ctx->nslot);
+  auto columns = [&]() -> int {                // the column kernel, on s2
+    hipLaunchKernelGGL((k_columns<TG, TO, TO>), dim3((unsigned)((B + 63) / 64)), dim3(64 * COL_WAVES), lds, s2, tabG, cstG,
+                       (const double*)atm, Bp, (const int*)ctx->band0, (const int*)ctx->band1, (const double*)ctx->frac,
+                       (const double*)ctx->coef, (const double*)ctx->econv, ctx->nb,
+                       (const TO*)(opt ? opt->rdry_in : nullptr), ctx->po, B, (TO*)R_TOC,
+                       (TO*)R_TOA, (TO*)L_TOA, (TO*)(opt ? opt->rsoil : nullptr), (TO*)(opt ? opt->La : nullptr));
     HIP_TRY(ctx, hipGetLastError());
     if (prof) HIP_TRY(ctx, hipEventRecord(ev[3], s2));
-    SensorTab stb{ctx->slot0, ctx->slot1, ctx->frac, ctx->coef, ctx->econv, ctx->nb, ctx->nslot};
-    // 4 waves (each walking every 4th band) per 64-sample workgroup: with one wave per band (13 for Sentinel-2) a
-    // CU holds a single workgroup and the kernel is 0.25 ms per 1M spectra slower (sweep 2..13: 2-4 equal)
-    const int nwave = ctx->nb < 4 ? ctx->nb : 4;
-    hipLaunchKernelGGL((k_sensor<TO, TG>), dim3((unsigned)((B + 63) / 64)), dim3(64 * nwave), lds, s2, stb, (const TG*)G,
-                       (const double*)atm, Bp, B, (TO*)R_TOC, (TO*)R_TOA, (TO*)L_TOA, (const TG*)(want_rsoil ? gs : nullptr),
-                       (TO*)(opt ? opt->rsoil : nullptr), (TO*)(opt ? opt->La : nullptr));
-    HIP_TRY(ctx, hipGetLastError());
-    if (prof) HIP_TRY(ctx, hipEventRecord(ev[4], s2));
     return SPART_OK;
   };
   auto band_kernels = [&]() -> int {           // the full-band kernel (+ the batch-mean reduction), on the caller's stream
@@ -692,8 +681,7 @@ int spart_ctx_destroy(spart_ctx* ctx) {
   if (!ctx) return SPART_OK;
   DeviceGuard g(ctx->device);
   (void)hipFree(ctx->tabF); (void)hipFree(ctx->tabD); (void)hipFree(ctx->Ea);
-  (void)hipFree(ctx->slot_band);
-  (void)hipFree(ctx->slot0); (void)hipFree(ctx->slot1); (void)hipFree(ctx->frac); (void)hipFree(ctx->coef);
+  (void)hipFree(ctx->band0); (void)hipFree(ctx->band1); (void)hipFree(ctx->frac); (void)hipFree(ctx->coef);
   (void)hipFree(ctx->econv);
   for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
   for (SideLane& l : ctx->lanes) {
@@ -756,18 +744,12 @@ int spart_ctx_create(spart_ctx** out, int device, const spart_tables* t) {
 
   // --- sensor block
   ctx->nb = t->nb;
-  std::vector<int> need(NTILE * TILE, -1);
   if (t->nb > 0) {
     std::vector<double> wl;
     wl_solar(wl);
-    std::vector<int> s0(t->nb), s1(t->nb);
+    std::vector<int> e0(t->nb), e1(t->nb);
     std::vector<double> fr(t->nb);
-    int nslot = 0;
-    auto slot_of = [&](int grid_idx) {
-      int ev = grid_idx < NWL ? grid_idx : NWL;   // every thermal grid point holds the same value
-      if (need[ev] < 0) need[ev] = nslot++;
-      return need[ev];
-    };
+    auto eval_of = [](int grid_idx) { return grid_idx < NWL ? grid_idx : NWL; };   // every thermal grid point holds the same value
     for (int j = 0; j < t->nb; ++j) {
       double x = t->wl_smac[j];
       // i0 = last grid point <= x, clipped to [0, n-2]; np.interp clamps outside the grid
@@ -777,20 +759,15 @@ int spart_ctx_create(spart_ctx** out, int device, const spart_tables* t) {
       double f = (x - wl[i0]) / (wl[i1] - wl[i0]);
       if (!(f > 0.0)) f = 0.0;
       if (f > 1.0) f = 1.0;
-      s0[j] = slot_of(i0);
-      s1[j] = f > 0.0 ? slot_of(i1) : s0[j];
+      e0[j] = eval_of(i0);
+      e1[j] = f > 0.0 ? eval_of(i1) : e0[j];
       fr[j] = f;
     }
-    ctx->nslot = nslot;
-    std::vector<int> sband(nslot > 0 ? nslot : 1, 0);
-    for (int ev = 0; ev < NTILE * TILE; ++ev)
-      if (need[ev] >= 0) sband[need[ev]] = ev;
-    if ((rc = upload(ctx, &ctx->slot_band, sband))) { spart_ctx_destroy(ctx); return rc; }
     std::vector<double> coef(t->coef, t->coef + (size_t)NCOEF * t->nb);
     std::vector<double> wsrf(t->wl_srf, t->wl_srf + (size_t)t->nsrf * t->nb), psrf(t->p_srf, t->p_srf + (size_t)t->nsrf * t->nb);
     double *d_w = nullptr, *d_p = nullptr;
     std::vector<double> ec(t->nb, 0.0);
-    if ((rc = upload(ctx, &ctx->slot0, s0)) || (rc = upload(ctx, &ctx->slot1, s1)) || (rc = upload(ctx, &ctx->frac, fr)) ||
+    if ((rc = upload(ctx, &ctx->band0, e0)) || (rc = upload(ctx, &ctx->band1, e1)) || (rc = upload(ctx, &ctx->frac, fr)) ||
         (rc = upload(ctx, &ctx->coef, coef)) || (rc = upload(ctx, &ctx->econv, ec)) || (rc = upload(ctx, &d_w, wsrf)) ||
         (rc = upload(ctx, &d_p, psrf))) {
       (void)hipFree(d_w); (void)hipFree(d_p);
@@ -845,10 +822,10 @@ int spart_profile_read_stages(spart_ctx* ctx, double stage_ms[SPART_NSTAGE], int
   for (size_t i = 0; i + NEV <= ctx->ev_used; i += NEV) {
     HIP_TRY(ctx, hipEventSynchronize(ctx->ev[i + 2]));
     HIP_TRY(ctx, hipEventSynchronize(ctx->ev[i + NEV - 1]));
-    // events: 0 before the prelude, 1 after it, 2 after the full-band kernel, 3 after the slot pass, 4 after the sensor
-    // kernel.  When 3 and 4 were recorded on the side stream the slot pass started at event 1, beside the band kernel.
+    // events: 0 before the prelude, 1 after it, 2 after the full-band kernel, 3 after the column kernel.  When 3 was
+    // recorded on the side stream the column kernel started at event 1, beside the band kernel.
     const bool forked = n < (int)ctx->ev_forked.size() && ctx->ev_forked[n];
-    const int from[SPART_NSTAGE] = {0, 1, forked ? 1 : 2, 3}, to[SPART_NSTAGE] = {1, 2, 3, 4};
+    const int from[SPART_NSTAGE] = {0, 1, forked ? 1 : 2}, to[SPART_NSTAGE] = {1, 2, 3};
     for (int k = 0; k < SPART_NSTAGE; ++k) {
       float ms = 0.f;
       HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[i + from[k]], ctx->ev[i + to[k]]));
@@ -878,7 +855,7 @@ int spart_calculate_tav(double alpha_deg, const double* nr, int64_t n, double* o
 
 size_t spart_workspace_bytes(const spart_ctx* ctx, int dtype, int64_t B) {
   if (!ctx || B <= 0) return 0;
-  return carve(dtype, B, ctx->nslot).total;
+  return carve(dtype, B).total;
 }
 
 #define CHECK_COMMON(name)                                                                                  \
@@ -887,7 +864,7 @@ size_t spart_workspace_bytes(const spart_ctx* ctx, int dtype, int64_t B) {
   if (dtype != SPART_F32 && dtype != SPART_F64) return fail(ctx, SPART_ERR_INVALID, name ": bad dtype %d", dtype); \
   if (B < 0) return fail(ctx, SPART_ERR_INVALID, name ": negative batch");                                  \
   if (B == 0) return SPART_OK;                                                                              \
-  Workspace ws = carve(dtype, B, ctx->nslot);                                                               \
+  Workspace ws = carve(dtype, B);                                                                           \
   if (!workspace || workspace_bytes < ws.total)                                                             \
     return fail(ctx, SPART_ERR_WORKSPACE, name ": workspace of %zu bytes needed, %zu given", ws.total, workspace_bytes); \
   DeviceGuard guard(ctx->device);                                                                           \

@@ -38,8 +38,8 @@ struct ParamPtrs {
 
 // ------------------------------------------------------------------------------------------
 // Workspace layout of the per-sample quantities: STRUCTURE OF ARRAYS with row pitch Bp (= B rounded up to 64):
-//   cst[i][s]  (NCONST = 40 rows, float and / or double), atm[i][s] (16 rows, double), G[slot][4][s], gsoil[slot][s].
-// Every kernel that has the sample on its lanes (prelude, sensor-slot pass, sensor kernel) then reads and writes
+//   cst[i][s]  (NCONST = 40 rows, 36 used, float and / or double), atm[i][s] (16 rows, 15 used, double).
+// Every kernel that has the sample on its lanes (prelude, column kernel) then reads and writes
 // them coalesced; the band kernels (band on lanes) stage 32 samples x 40 constants per workgroup copy.
 inline int64_t row_pitch_of(int64_t B) { return (B + 63) & ~int64_t(63); }
 
@@ -119,10 +119,46 @@ struct PreludeStore {            // sample_prelude_to's sink: straight to the st
 #ifndef SPART_PRELUDE_WAVES
 #define SPART_PRELUDE_WAVES 3     // waves per SIMD the prelude is compiled for (168 VGPRs, a handful of spilled values)
 #endif
+// Which lane takes which sample of the workgroup's 256: the literal LIDF iteration (sailh.py:378-382) runs 12 fixed-point
+// solves per sample whose pass counts differ from sample to sample -- 6 passes on average, 15 for the slowest of 64 lanes,
+// and a wave pays its slowest lane.  The pass count grows with |LIDFa| + |LIDFb| (the contraction rate of the iteration), so
+// the workgroup's samples are dealt to its four waves IN THE ORDER OF THAT KEY (a 32-bucket counting sort in LDS, ~60
+// instructions): the slowest lane of a wave then has 10.9 passes on average (host-side emulation of the wave, 65 536 rows of
+// the benchmark's distribution; 1024-sample groups would give 9.9).  A sample's arithmetic does not depend on the lane that
+// runs it: results are bit-identical with and without the permutation.  Rows stay coalesced at the cache-line level (a
+// workgroup still reads / writes one 2 KB segment of every row).
+#ifndef SPART_PRELUDE_SORT
+#define SPART_PRELUDE_SORT 1
+#endif
 template <bool FAST>
 __global__ __launch_bounds__(256, SPART_PRELUDE_WAVES) void k_prelude(ParamPtrs pp, int mask, int64_t B, int64_t Bp, float* __restrict__ cstF,
                                                  double* __restrict__ cstD, double* __restrict__ atm) {
-  int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t base = (int64_t)blockIdx.x * blockDim.x;
+  int64_t s = base + threadIdx.x;
+  if (SPART_PRELUDE_SORT && !FAST && (mask & PRE_CANOPY)) {      // (block-uniform condition)
+    constexpr int NB = 32;
+    __shared__ int cnt[NB], start[NB];
+    __shared__ unsigned char perm[256];
+    const int t = threadIdx.x;
+    int bucket = NB - 1;                                       // lanes past the end of the batch: last, so that whole waves idle
+    if (s < B) {
+      const double key = ::fabs(pp.p[16][s]) + ::fabs(pp.p[17][s]);     // |LIDFa| + |LIDFb| (valid inputs: <= ~1.5)
+      const double q = key * (NB / 1.0);
+      bucket = !(q < (double)(NB - 1)) ? NB - 1 : (q > 0.0 ? (int)q : 0);   // (NaN -> last bucket)
+    }
+    if (t < NB) cnt[t] = 0;
+    __syncthreads();
+    const int pos = atomicAdd(&cnt[bucket], 1);
+    __syncthreads();
+    if (t == 0) {
+      int acc = 0;
+      for (int i = 0; i < NB; ++i) { start[i] = acc; acc += cnt[i]; }
+    }
+    __syncthreads();
+    perm[start[bucket] + pos] = (unsigned char)t;
+    __syncthreads();
+    s = base + perm[t];
+  }
   if (s >= B) return;
   double rho_th = pp.rho_th ? pp.rho_th[s] : 0.01;  // LeafBiology defaults (prospect_5d.py:82-83)
   double tau_th = pp.tau_th ? pp.tau_th[s] : 0.01;
@@ -217,7 +253,7 @@ template <typename T> struct MatPtrs {
 // memory (spart_math.h, E3c<double>) three fit with 38 spilled values: 36.2 ms (with the coefficients as literals
 // three workgroups meant 96 spilled values and 104 ms).
 // The sensor columns never come from this kernel: in every mode R_TOC / R_TOA / L_TOA (and the debug rsoil column) are
-// produced by k_slots -> k_sensor from the <= 2 nb bands they depend on, so that they are the SAME numbers -- by
+// produced by k_columns from the <= 2 nb bands they depend on, so that they are the SAME numbers -- by
 // construction, not by compiler luck -- whether the full spectra are evaluated in float64, in float32, or not at all.
 template <typename T, int MAT, int FULL, bool NT = false>
 __global__ __launch_bounds__(TILE, (sizeof(T) == 8 ? 3 : 1))
@@ -408,64 +444,153 @@ void k_bands(const T* __restrict__ tab, const T* __restrict__ cst, int64_t Bp, i
   }
 }
 
-// The sensor-slot pass: only the <= 2 nb bands the sensor columns depend on are evaluated.  Lane = sample; the band's 17
-// table values are wave-uniform (scalar loads), the G rows are written coalesced (structure of arrays); the mapping of
-// samples and slots to workgroups is described at the kernel.  Identical arithmetic (leaf_band / soil_band /
-// canopy_band), ~150x less work than k_bands.  Two uses:
-//   * T = double in the default float32 mode: the G rows (and the debug rsoil values) that k_sensor turns into
-//     R_TOC / R_TOA / L_TOA are float64 whatever the dtype of the full-band kernel, so the float32 mode's columns are
-//     the float64 mode's columns rounded once (near-conservative PRO leaves make the
-//     reference's canopy formulas cancel, sailh.py:185-214, and float32 band arithmetic then misses 1e-4);
-//   * spart_materialize.prune_unused_bands = 1 (NOT "full spectra"): the full-band kernel is skipped altogether.
-// TR: element type of the optional user dry-soil spectra (they arrive in the call's dtype).
-// a sample's constants in LDS as [NCONST][64] (lane = sample): p points at this lane's column
+// ------------------------------------------------------------------------------------------
+// K3: THE COLUMN KERNEL.  R_TOC / R_TOA / L_TOA (and the debug rsoil column, La) of every sample, from the <= 2 nb
+// spectral bands they depend on: for each sensor band the canopy model (PROSPECT + BSM + SAILH, the arithmetic of
+// leaf_band / soil_band / canopy_core / canopy_soil that k_bands runs for all 2162 bands) is evaluated at the np.interp
+// support points of the band centre (SPART.py:220-223: one grid point for the integer centres of Sentinel-2 / Landsat 4,
+// 5, 8, two for the fractional centres of MODIS / OLCI / Landsat 7), interpolated, and taken through SMAC (smac.py) and
+// TOC -> TOA (SPART.py:243-252) IN THE SAME WAVE: the four canopy reflectances never leave registers.  (Rounds 1-4 ran
+// this as two kernels -- a sensor-slot pass writing a (nslot, 4, B) float64 array, a sensor kernel reading it back:
+// 0.83 GB of the pruned step's 2.16 GB per 1M spectra and a launch.)
+// In EVERY mode of spart_run_batch the columns come from this kernel, so they are the SAME numbers -- by construction --
+// whether the full spectra are evaluated beside it in float64, in float32, or not at all (prune_unused_bands).
+//   TG: arithmetic of the canopy model (double, except spart_materialize.f32_columns); SMAC and TOC -> TOA are float64
+//   TO: dtype of the (B, nb) outputs;  TR: element type of the optional user dry-soil spectra (the call's dtype).
+// Mapping: a workgroup owns 64 consecutive samples (lane = sample); its 36 band constants and 15 atmosphere scalars
+// are copied into LDS once ([row][64]: lane l reads word l of a row, conflict-free) and wave w walks the sensor bands
+// j = w, w + 4, ...: the band index -- and with it the 17 table values, the 48 SMAC coefficients, the interpolation
+// support and the "is this gas absent in this band" tests -- is wave-uniform (scalar loads, scalar branches).
 template <typename T> struct LdsCol {
   const T* p;
   __device__ __forceinline__ T operator[](int i) const { return p[i * 64]; }
 };
 
-// One workgroup = 64 samples (lane = sample) x 4 waves; the block's 40 x 64 constants are copied into LDS once and wave w
-// walks the slots w, w + 4, ...: every slot's band arithmetic then reads its 36 constants from LDS (conflict-free: lane l
-// reads word l of a row) instead of pulling them through L2 again -- with one workgroup per (256 samples, slot) the
-// kernel moved nslot x 288 B per sample from L2 and was bound by that (0.35 ms per 1M; 0.13 ms of float64 arithmetic).
-template <typename T, typename TR>
-__global__ __launch_bounds__(256) void k_slots(const T* __restrict__ tab, const T* __restrict__ cst, int64_t Bp,
-                                               const int* __restrict__ slot_band, T* __restrict__ G,
-                                               T* __restrict__ gsoil, const TR* __restrict__ rdry_in, int po, int64_t B,
-                                               int nslot) {
-  __shared__ T lds_c[NCONST * 64];
-  if (sizeof(T) == 8) stage_f64_tables();
+// band0 / band1: (nb) evaluation index (0..2000 = 400..2400 nm, 2001 = the thermal evaluation) of the grid point at / below
+// the band centre, and of the next grid point (== band0 where the centre sits on a grid point, frac == 0).  The sensor
+// tables are separate __restrict__ arguments (a pointer inside a by-value struct cannot be declared noalias).
+
+constexpr int COL_WAVES = 4;   // (more waves per 64-sample workgroup measured slower for both former kernels)
+#ifndef SPART_COLUMNS_WAVES
+#define SPART_COLUMNS_WAVES 4  // waves per SIMD the column kernel is compiled for (128 VGPRs)
+#endif
+// Results leave straight from the lane that computed them (stride nb between lanes: the (64 x nb) block of a workgroup is
+// completed by its four waves within a few hundred cycles and merges in L2) instead of through an LDS transpose: the 10 KB
+// of staging were what limited the kernel to three workgroups per CU.
+#ifndef SPART_COLUMNS_DIRECT
+#define SPART_COLUMNS_DIRECT 1
+#endif
+
+template <typename TG, typename TO, typename TR>
+__global__ __launch_bounds__(64 * COL_WAVES, SPART_COLUMNS_WAVES) void k_columns(
+    const TG* __restrict__ tab, const TG* __restrict__ cst, const double* __restrict__ atm, int64_t Bp,
+    const int* __restrict__ band0, const int* __restrict__ band1, const double* __restrict__ frac,
+    const double* __restrict__ coef, const double* __restrict__ econv, int nb, const TR* __restrict__ rdry_in, int po, int64_t B,
+    TO* __restrict__ R_TOC, TO* __restrict__ R_TOA, TO* __restrict__ L_TOA, TO* __restrict__ o_rsoil, TO* __restrict__ o_La) {
+  constexpr bool DIRECT = SPART_COLUMNS_DIRECT != 0;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  TO* stage = reinterpret_cast<TO*>(smem_raw);          // [narr][64 * nb]  (not used with DIRECT)
+  __shared__ TG lds_c[NCONST_USED * 64];
+  __shared__ double lds_a[NATM_USED * 64];
+  __shared__ double lds_k[COL_WAVES * 64];              // per wave: the 48 SMAC coefficients of the band it is working on
+  if (sizeof(TG) == 8 || !SPART_SMAC_LIBM) stage_f64_tables();   // exp / log tables of the float64 arithmetic
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int64_t s = (int64_t)blockIdx.x * 64 + lane;
-  const int64_t sc = s < B ? s : B - 1;
-  constexpr int nwave = 4;                   // (more waves per workgroup measured slower: 7 / 13 / 16 -> +17 / +35 / +34 %)
-  for (int i = wave; i < NCONST; i += nwave) lds_c[i * 64 + lane] = cst[(int64_t)i * Bp + sc];
+  const int64_t s0 = (int64_t)blockIdx.x * 64;
+  const int64_t s = s0 + lane;
+  const bool ok = s < B;
+  const int64_t sc = ok ? s : B - 1;                    // (lanes past the end repeat the last sample and store nothing)
+  for (int i = wave; i < NCONST_USED; i += COL_WAVES) lds_c[i * 64 + lane] = cst[(int64_t)i * Bp + sc];
+  for (int i = wave; i < NATM_USED; i += COL_WAVES) lds_a[i * 64 + lane] = atm[(int64_t)i * Bp + sc];
   __syncthreads();
-  if (s >= B) return;                                            // (no barrier below)
-  const LdsCol<T> c{lds_c + lane};
-  for (int q = wave; q < nslot; q += nwave) {
-    const int band = slot_band[q];
-    const bool thermal = band == NWL;
-    const int ti = band < NWL ? band : NWL - 1;
-    const BandTab<T> tb = load_tab(tab, ti);
-    T refl, tran, absb, K;
-    leaf_band<T>(tb, c[C_CAB], c[C_CCA], c[C_CDM], c[C_CW], c[C_CS], c[C_CANT], c[C_CBC], c[C_PROT], c[C_NM1], refl,
-                 tran, absb, K);
-    T rho = thermal ? c[C_RHO_TH] : refl;
-    T tau = thermal ? c[C_TAU_TH] : tran;
-    T ab = thermal ? (T(1) - c[C_RHO_TH] - c[C_TAU_TH]) : absb;
-    const CanopyPar<T> cp = load_canopy<T>(c);                   // (same order of the parts as in k_bands)
-    const CanopyCore<T> core = canopy_core<T>(cp, rho, tau, ab);
-    T rdry = rdry_in ? (T)rdry_in[s * po + ti] : soil_dry<T>(tb, c[C_F1], c[C_F2], c[C_F3]);
-    T fm[7] = {c[C_FM0], c[C_FM1], c[C_FM2], c[C_FM3], c[C_FM4], c[C_FM5], c[C_FM6]};
-    T rwet;
-    soil_band<T>(tb, rdry, c[C_WET], fm, c[C_FMSUM], c[C_FILM2L], rwet);
-    T rso, rdo, rsd, rdd;
-    canopy_soil<T>(cp, core, rwet, rso, rdo, rsd, rdd);
-    T* g = G + (int64_t)q * 4 * Bp + s;
-    g[0] = rso; g[Bp] = rdo; g[2 * Bp] = rsd; g[3 * Bp] = rdd;
-    if (gsoil) gsoil[(int64_t)q * Bp + s] = rwet;
+  const LdsCol<TG> c{lds_c + lane};
+  const LdsCol<double> a{lds_a + lane};
+  const int tile = 64 * nb;
+  const bool want_soil = o_rsoil != nullptr;
+  // (starting wave w at band (w + workgroup) mod 4, so that the four-band wave of a 13-band sensor moves from SIMD to SIMD,
+  //  changed nothing: 0.464 / 0.466 ms, profiles/r5_ab_columns.txt)
+  for (int j = wave; j < nb; j += COL_WAVES) {
+    const int b0 = band0[j], b1 = band1[j];
+    const double f = frac[j];
+    // this band's 48 SMAC coefficients: ONE vector load (lane r fetches row r), issued before the canopy model and parked in
+    // the wave's LDS row behind it; smac_band then reads each with a wave-uniform (broadcast) ds_read.  Left to the
+    // compiler they were ~50 dependent global loads per band, each followed by its own s_waitcnt vmcnt(0).
+    const double kv = coef[(size_t)(lane < NCOEF ? lane : NCOEF - 1) * nb + j];
+    double y0[5], y1[5];                                // rso, rdo, rsd, rdd, wet soil at the two support points
+#pragma unroll 1
+    for (int e = 0; e < 2; ++e) {
+      if (e == 1 && b1 == b0) break;                    // (wave-uniform)
+      const int band = e ? b1 : b0;
+      const bool thermal = band == NWL;
+      const int ti = band < NWL ? band : NWL - 1;       // thermal soil = soil at 2400 nm (SPART.py:440)
+      const BandTab<TG> tb = load_tab(tab, ti);
+      TG refl, tran, absb, K;
+      leaf_band<TG>(tb, c[C_CAB], c[C_CCA], c[C_CDM], c[C_CW], c[C_CS], c[C_CANT], c[C_CBC], c[C_PROT], c[C_NM1], refl,
+                    tran, absb, K);
+      const TG rho = thermal ? c[C_RHO_TH] : refl;      // SPART.py:463-466
+      const TG tau = thermal ? c[C_TAU_TH] : tran;
+      const TG ab = thermal ? (TG(1) - c[C_RHO_TH] - c[C_TAU_TH]) : absb;
+      const CanopyPar<TG> cp = load_canopy<TG>(c);      // (same order of the parts as in k_bands)
+      const CanopyCore<TG> core = canopy_core<TG>(cp, rho, tau, ab);
+      const TG rdry = rdry_in ? (TG)rdry_in[sc * po + ti] : soil_dry<TG>(tb, c[C_F1], c[C_F2], c[C_F3]);
+      TG fm[7] = {c[C_FM0], c[C_FM1], c[C_FM2], c[C_FM3], c[C_FM4], c[C_FM5], c[C_FM6]};
+      TG rwet;
+      soil_band<TG>(tb, rdry, c[C_WET], fm, c[C_FMSUM], c[C_FILM2L], rwet);
+      TG rso, rdo, rsd, rdd;
+      canopy_soil<TG>(cp, core, rwet, rso, rdo, rsd, rdd);
+      const double v[5] = {(double)rso, (double)rdo, (double)rsd, (double)rdd, (double)rwet};
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        if (e == 0) y0[q] = v[q];
+        y1[q] = v[q];                                   // (one support point: y1 = y0, as np.interp sees it)
+      }
+    }
+    double v[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) v[q] = y0[q] + (y1[q] - y0[q]) * f;    // np.interp (SPART.py:220-223)
+    double* kw = lds_k + wave * 64;
+    kw[lane] = kv;                                       // (LDS serves a wave's instructions in order: the reads below see it)
+    const SmacOut so = smac_band_c(a, [kw](int r) { return kw[r]; });
+    const double La = a[A_LAF] * econv[j];               // SPART.py:353, 394
+    double rtoc, rtoa, ltoa;
+    toc_to_toa(so, v[0], v[1], v[3], v[2], La, rtoc, rtoa, ltoa);
+    if (DIRECT) {
+      if (ok) {
+        const int64_t o = s * nb + j;
+        R_TOC[o] = (TO)rtoc;
+        R_TOA[o] = (TO)rtoa;
+        L_TOA[o] = (TO)ltoa;
+        if (want_soil) o_rsoil[o] = (TO)v[4];           // SPART.py:262-267
+        if (o_La) o_La[o] = (TO)La;
+      }
+    } else {
+      const int o = lane * nb + j;
+      stage[o] = (TO)rtoc;
+      stage[tile + o] = (TO)rtoa;
+      stage[2 * tile + o] = (TO)ltoa;
+      int na = 3;
+      if (want_soil) {
+        stage[na * tile + o] = (TO)v[4];
+        ++na;
+      }
+      if (o_La) stage[na * tile + o] = (TO)La;
+    }
+  }
+  if (DIRECT) return;
+  __syncthreads();
+  const int64_t rem = B - s0;
+  const int n = (int)((rem < 64 ? rem : 64) * nb);
+  const int64_t base = s0 * nb;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    R_TOC[base + i] = stage[i];
+    R_TOA[base + i] = stage[tile + i];
+    L_TOA[base + i] = stage[2 * tile + i];
+    int na = 3;
+    if (want_soil) {
+      o_rsoil[base + i] = stage[na * tile + i];
+      ++na;
+    }
+    if (o_La) o_La[base + i] = stage[na * tile + i];
   }
 }
 
@@ -619,93 +744,13 @@ __global__ __launch_bounds__(TILE) void k_sailh(const T* __restrict__ cst, int64
 }
 
 // ------------------------------------------------------------------------------------------
-// K3: one lane per (sample, sensor band): np.interp to the band centre (SPART.py:220-223),
-// SMAC (smac.py), TOC -> TOA (SPART.py:243-252).  float64 arithmetic, outputs in T.
-struct SensorTab {
-  const int* slot0;      // (nb) slot of the grid point at/below the centre
-  const int* slot1;      // (nb) slot of the next grid point
-  const double* frac;    // (nb)
-  const double* coef;    // (48, nb)
-  const double* econv;   // (nb)
-  int nb, nslot;
-};
-
-// Mapping: a workgroup owns 64 consecutive samples (lane = sample); wave w walks the sensor bands
-// j = w, w + nwave, ... so that the band index -- and with it the 48 SMAC coefficients, the interpolation
-// slots and the "is this gas absent in this band" tests -- is wave-uniform (scalar loads, scalar branches).
-// Results are staged in LDS and written out as whole (64 x nb) row blocks, coalesced.
-// G rows and rsoil slots are structure-of-arrays as k_slots (sample on lanes) writes them: G[slot][4][Bp], gsoil[slot][Bp].
-// TG: element type of the G rows / gsoil values (double in the default float32 mode, see k_slots).  atm is
-// structure-of-arrays with pitch Bp.
-template <typename T, typename TG>
-__global__ __launch_bounds__(1024) void k_sensor(SensorTab st, const TG* __restrict__ G,
-                                                 const double* __restrict__ atm, int64_t Bp, int64_t B, T* __restrict__ R_TOC, T* __restrict__ R_TOA,
-                                                 T* __restrict__ L_TOA, const TG* __restrict__ gsoil,
-                                                 T* __restrict__ o_rsoil, T* __restrict__ o_La) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* stage = reinterpret_cast<T*>(smem_raw);          // [narr][64 * nb]
-  const int nb = st.nb;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int nwave = (int)(blockDim.x >> 6);
-  const int64_t s0 = (int64_t)blockIdx.x * 64;
-  const int64_t s = s0 + lane;
-  const bool ok = s < B;
-  const int64_t sc = ok ? s : B - 1;
-  double a[NATM];
-#pragma unroll
-  for (int i = 0; i < NATM; ++i) a[i] = atm[i * Bp + sc];
-  const int tile = 64 * nb;
-  for (int j = wave; j < nb; j += nwave) {
-    const int sl0 = st.slot0[j], sl1 = st.slot1[j];
-    const double f = st.frac[j];
-    const TG* g0 = G + (int64_t)sl0 * 4 * Bp + sc;
-    const TG* g1 = G + (int64_t)sl1 * 4 * Bp + sc;
-    double v[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      double y0 = (double)g0[q * Bp], y1 = (double)g1[q * Bp];
-      v[q] = y0 + (y1 - y0) * f;                     // np.interp (SPART.py:220-223)
-    }
-    SmacOut so = smac_band(a, st.coef + j, nb);
-    double La = a[A_LAF] * st.econv[j];              // SPART.py:353, 394
-    double rtoc, rtoa, ltoa;
-    toc_to_toa(so, v[0], v[1], v[3], v[2], La, rtoc, rtoa, ltoa);  // G order: rso, rdo, rsd, rdd
-    const int o = lane * nb + j;
-    stage[o] = (T)rtoc;
-    stage[tile + o] = (T)rtoa;
-    stage[2 * tile + o] = (T)ltoa;
-    int na = 3;
-    if (o_rsoil && gsoil) {
-      double y0 = (double)gsoil[(int64_t)sl0 * Bp + sc], y1 = (double)gsoil[(int64_t)sl1 * Bp + sc];
-      stage[na * tile + o] = (T)(y0 + (y1 - y0) * f);
-      ++na;
-    }
-    if (o_La) stage[na * tile + o] = (T)La;
-  }
-  __syncthreads();
-  const int64_t rem = B - s0;
-  const int n = (int)((rem < 64 ? rem : 64) * nb);
-  const int64_t base = s0 * nb;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    R_TOC[base + i] = stage[i];
-    R_TOA[base + i] = stage[tile + i];
-    L_TOA[base + i] = stage[2 * tile + i];
-    int na = 3;
-    if (o_rsoil && gsoil) {
-      o_rsoil[base + i] = stage[na * tile + i];
-      ++na;
-    }
-    if (o_La) o_La[base + i] = stage[na * tile + i];
-  }
-}
-
 // standalone SMAC: nine (B,nb) float64 outputs
 struct Out9 {
   double* o[9];
 };
 static __global__ __launch_bounds__(256) void k_smac(const double* __restrict__ coef, int nb, const double* __restrict__ atm,
                                               int64_t Bp, int64_t B, Out9 out) {
+  if (!SPART_SMAC_LIBM) stage_f64_tables();             // smac_band's table exp
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * nb) return;
   int64_t s = i / nb;

@@ -250,6 +250,15 @@ template <> struct Mx<double> {
     r = __builtin_fma(-k, 2.9064910585985925e-13, r);                    // low part
     return exp_finish(k, r);
   }
+  // the same for callers that rely on exp(NaN) = NaN (smac_band: a NaN gas column reaches the result only through exp);
+  // a compare + select instead of the one v_max
+  static SPART_HD double exp_keepnan(double x) {
+    x = (x < -800.0) ? -800.0 : x;
+    const double k = __builtin_rint(x * 369.32993046757463);
+    double r = __builtin_fma(-k, 0.0027076061737716373, x);
+    r = __builtin_fma(-k, 2.9064910585985925e-13, r);
+    return exp_finish(k, r);
+  }
   static SPART_HD double exp2(double x) {                  // 2^x = 2^(k/256) e^((256 x - k) ln2 / 256)
     const double t = x * 256.0;
     const double k = __builtin_rint(t);
@@ -273,6 +282,7 @@ template <> struct Mx<double> {
 #else
   static SPART_HD double exp_poly(double x) { return ::exp(x); }
   static SPART_HD double exp(double x) { return ::exp(x); }
+  static SPART_HD double exp_keepnan(double x) { return ::exp(x); }
   static SPART_HD double exp2(double x) { return ::exp2(x); }
   static SPART_HD double log(double x) { return ::log(x); }
 #endif
@@ -568,6 +578,7 @@ enum ConstIdx {
   C_RSV0, C_RSV1, C_RSV2, C_RSV3,
   NCONST  // 40: 36 used, padded to a multiple of 8 (stage_constants)
 };
+constexpr int NCONST_USED = C_RSV0;   // rows the prelude writes
 static_assert(NCONST == 40, "constant block is 40 values");
 
 // per-sample atmosphere scalars (double), read by the sensor-band kernel
@@ -577,6 +588,7 @@ enum AtmIdx {
   A_RSV,
   NATM  // 16
 };
+constexpr int NATM_USED = A_RSV;      // rows the prelude writes
 
 // ------------------------------------------------------------------------------------------
 // PROSPECT-5D / PRO, one band                                        (prospect_5d.py:170-241)
@@ -1321,9 +1333,30 @@ enum CoefRow {
   K_REST4, K_RESR1, K_RESR2, K_RESR3, K_RESA1, K_RESA2, K_RESA3, K_RESA4
 };
 
-SPART_HD SmacOut smac_band(const double* atm, const double* coef, int cs) {
-  auto C = [&](int r) { return coef[(size_t)r * cs]; };
+// atm: anything indexable by AtmIdx (a plain array of NATM doubles, or a sample's column of the LDS copy in k_columns)
+// C(r): coefficient row r (CoefRow) of this band
+template <typename A, typename CF> SPART_HD SmacOut smac_band_c(const A& atm, const CF& C) {
   using Md = Mx<double>;
+  // exp / sqrt: the library's (default), or with SPART_SMAC_LIBM=0 the float64 band arithmetic's own table-driven exp (LDS
+  // tables staged by the calling kernel: stage_f64_tables) and Newton-refined rsq: 17 % fewer instructions, more registers
+#ifndef SPART_SMAC_LIBM
+#define SPART_SMAC_LIBM 1     // measured: the table exp needs 168 VGPRs here (three waves per SIMD: 0.51 ms per 1M spectra, spilling at
+#endif                        // 128: 0.95 ms) against 0.47 ms with the library's exp at 128 (profiles/r5_ab_smac_exp.txt)
+#if SPART_SMAC_LIBM
+  auto EXP = [](double x) { return ::exp(x); };
+  auto SQRT = [](double x) { return ::sqrt(x); };
+#else
+  // (a scheduling barrier behind each exp: left free, the scheduler interleaves the thirteen independent table-exp chains
+  //  and the kernel needs 168 VGPRs instead of 128)
+  auto EXP = [](double x) {
+    const double r = Md::exp_keepnan(x);
+#if defined(__HIP_DEVICE_COMPILE__) && defined(SPART_SMAC_SCHED_BARRIER) && SPART_SMAC_SCHED_BARRIER
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    return r;
+  };
+  auto SQRT = [](double x) { return Md::sqrt(x); };
+#endif
   double us = atm[A_US], uv = atm[A_UV], m = atm[A_M], Peq = atm[A_PEQ], Pa = atm[A_PA];
   double taup550 = atm[A_AOT], cksi = atm[A_CKSI], ksiD = atm[A_KSID];
   double lpeq = atm[A_LOGPEQ], lm = atm[A_LOGM];
@@ -1335,11 +1368,11 @@ SPART_HD SmacOut smac_band(const double* atm, const double* coef, int cs) {
   // bands): it is skipped, which leaves the product below bit-identical.
   auto gas = [&](int ka, int kn, double lum) -> double {
     double av = C(ka);
-    return (av != 0.0) ? ::exp(av * ::exp(C(kn) * lum)) : 1.0;
+    return (av != 0.0) ? EXP(av * EXP(C(kn) * lum)) : 1.0;
   };
   auto pgas = [&](int ka, int kn, int kp) -> double {
     double av = C(ka);
-    return (av != 0.0) ? ::exp(av * ::exp(C(kn) * (C(kp) * lpeq + lm))) : 1.0;
+    return (av != 0.0) ? EXP(av * EXP(C(kn) * (C(kp) * lpeq + lm))) : 1.0;
   };
   double to3 = gas(K_AO3, K_NO3, atm[A_LOGO3M]);
   double th2o = gas(K_AH2O, K_NH2O, atm[A_LOGH2OM]);
@@ -1358,7 +1391,7 @@ SPART_HD SmacOut smac_band(const double* atm, const double* coef, int cs) {
   double iusuv = ius * iuv;
   double ray_phase = 0.7190443 * (1.0 + (cksi * cksi)) + 0.0412742;  // :141
   double ray_ref = (taur * ray_phase) * (0.25 * iusuv);              // :142
-  ray_ref = ray_ref * Pa / 1013.25;                                  // :143
+  ray_ref = ray_ref * Pa * (1.0 / 1013.25);                          // :143 (a multiplication: <= 1 ulp from the division)
   double taurz = taur * Peq;                                         // :144
   double aer_phase = C(K_A0P) + C(K_A1P) * ksiD + C(K_A2P) * ksiD * ksiD + C(K_A3P) * ksiD * ksiD * ksiD +
                      C(K_A4P) * (ksiD * ksiD) * (ksiD * ksiD);  // :146-148
@@ -1366,20 +1399,21 @@ SPART_HD SmacOut smac_band(const double* atm, const double* coef, int cs) {
   double g3 = 3.0 - wo * 3.0 * gc;
   double ig3 = Md::rcp(g3);
   double ak2 = (1.0 - wo) * g3;  // :149-150
-  double ak = ::sqrt(ak2);
+  double ak = SQRT(ak2);
   double idus = Md::rcp(1.0 - ak2 * us * us);
   double e = -3.0 * us * us * wo * 0.25 * idus;  // :153-157
   double f = -(1.0 - wo) * 3.0 * gc * us * us * wo * 0.25 * idus;
   double dp = e * ius * (1.0 / 3.0) + us * f;
   double d = e + f;
   double b = 2.0 * ak * ig3;
-  double eak = ::exp(ak * taup), emak = Md::rcp(eak);
+  double eak = EXP(ak * taup), emak = Md::rcp(eak);
   double delta = eak * (1.0 + b) * (1.0 + b) - emak * (1.0 - b) * (1.0 - b);  // :158
   double ww = wo * 0.25;
   double ss = us * idus;
   double q1 = 2.0 + 3.0 * us + (1.0 - wo) * 3.0 * gc * us * (1.0 + 2.0 * us);
   double q2 = 2.0 - 3.0 * us - (1.0 - wo) * 3.0 * gc * us * (1.0 - 2.0 * us);
-  double q3 = q2 * ::exp(-taup * ius);
+  const double e_us = EXP(-taup * ius);      // e^(-taup / us)
+  double q3 = q2 * e_us;
   double wsd = ww * ss * Md::rcp(delta);
   double c1 = wsd * (q1 * eak * (1.0 + b) + q3 * (1.0 - b));    // :164
   double c2 = -wsd * (q1 * emak * (1.0 - b) + q3 * (1.0 + b));  // :165
@@ -1391,9 +1425,19 @@ SPART_HD SmacOut smac_band(const double* atm, const double* coef, int cs) {
   // aa1 = uv/(1 + ak uv), aa2 = uv/(1 - ak uv), aa3 = us uv/(us + uv); taup/aa_i needs no division
   double n1 = 1.0 + ak * uv, n2 = 1.0 - ak * uv, n3 = us + uv;
   double aa1 = uv * Md::rcp(n1), aa2 = uv * Md::rcp(n2), aa3 = us * uv * Md::rcp(n3);
-  double aer_ref1 = x * aa1 * (1.0 - ::exp(-taup * n1 * iuv));  // :175-179
-  double aer_ref2 = y * aa2 * (1.0 - ::exp(-taup * n2 * iuv));
-  double aer_ref3 = z * aa3 * (1.0 - ::exp(-taup * n3 * iusuv));
+  // taup n1 / uv = taup / uv + ak taup, taup n2 / uv = taup / uv - ak taup, taup n3 / (us uv) = taup / uv + taup / us: the three
+  // exponentials of :175-179 are products of e^(-taup / uv) with e^(-+ ak taup) and e^(-taup / us), which :158 and :163 need
+  // anyway -- one exp instead of three, each product within 2 ulp of the direct exponential
+#if defined(SPART_SMAC_SHARE_EXP) && !SPART_SMAC_SHARE_EXP
+  double aer_ref1 = x * aa1 * (1.0 - EXP(-taup * n1 * iuv));  // :175-179
+  double aer_ref2 = y * aa2 * (1.0 - EXP(-taup * n2 * iuv));
+  double aer_ref3 = z * aa3 * (1.0 - EXP(-taup * n3 * iusuv));
+#else
+  const double e_uv = EXP(-taup * iuv);
+  double aer_ref1 = x * aa1 * (1.0 - e_uv * emak);  // :175-179
+  double aer_ref2 = y * aa2 * (1.0 - e_uv * eak);
+  double aer_ref3 = z * aa3 * (1.0 - e_uv * e_us);
+#endif
   double aer_ref = (aer_ref1 + aer_ref2 + aer_ref3) * iusuv;
   double rr = taur * ray_phase * iusuv;
   double Res_ray = C(K_RESR1) + C(K_RESR2) * rr + C(K_RESR3) * (rr * rr);  // :182-186
@@ -1403,20 +1447,26 @@ SPART_HD SmacOut smac_band(const double* atm, const double* coef, int cs) {
   double tt = tautot * m * cksi;
   double Res_6s = (C(K_REST1) + C(K_REST2) * tt + C(K_REST3) * (tt * tt)) + C(K_REST4) * (tt * tt * tt);  // :196-198
   o.Ra_so = ray_ref - Res_ray + aer_ref - Res_aer + Res_6s;  // :201
-  o.Ta_ss = ::exp(-tautot * ius);                            // :204-207
-  o.Ta_oo = ::exp(-tautot * iuv);
+  o.Ta_ss = EXP(-tautot * ius);                            // :204-207
+  o.Ta_oo = EXP(-tautot * iuv);
   o.Ta_sd = o.Ta_s - o.Ta_ss;
   o.Ta_do = o.Ta_o - o.Ta_oo;
   return o;
+}
+// the same with the coefficients in a (48, cs) row-major block: coef points at this band's column
+template <typename A> SPART_HD SmacOut smac_band(const A& atm, const double* coef, int cs) {
+  return smac_band_c(atm, [coef, cs](int r) { return coef[(size_t)r * cs]; });
 }
 
 // TOC -> TOA (SPART.py:243-252)
 SPART_HD void toc_to_toa(const SmacOut& a, double rv_so, double rv_do, double rv_dd, double rv_sd, double La,
                          double& R_TOC, double& R_TOA, double& L_TOA) {
+  using Md = Mx<double>;
+  const double imr = Md::rcp(1.0 - rv_dd * a.Ra_dd);          // (device: v_rcp_f64 + one Newton step, 2e-15 relative)
   double rtoa0 = a.Ra_so + a.Ta_ss * rv_so * a.Ta_oo;
-  double rtoa1 = (a.Ta_sd * rv_do + a.Ta_ss * rv_sd * a.Ra_dd * rv_do) * a.Ta_oo / (1.0 - rv_dd * a.Ra_dd);
-  double rtoa2 = (a.Ta_ss * rv_sd + a.Ta_sd * rv_dd) * a.Ta_do / (1.0 - rv_dd * a.Ra_dd);
-  R_TOC = (a.Ta_ss * rv_so + a.Ta_sd * rv_do) / (a.Ta_ss + a.Ta_sd);
+  double rtoa1 = (a.Ta_sd * rv_do + a.Ta_ss * rv_sd * a.Ra_dd * rv_do) * a.Ta_oo * imr;
+  double rtoa2 = (a.Ta_ss * rv_sd + a.Ta_sd * rv_dd) * a.Ta_do * imr;
+  R_TOC = (a.Ta_ss * rv_so + a.Ta_sd * rv_do) * Md::rcp(a.Ta_ss + a.Ta_sd);
   R_TOA = a.Tg * (rtoa0 + rtoa1 + rtoa2);
   L_TOA = La * R_TOA;
 }

@@ -58,7 +58,7 @@ SIGNATURES = {
     "spart_profile_read": (ctypes.c_int, [vp, c_dp, ctypes.POINTER(ctypes.c_int)]),
     "spart_profile_read_stages": (ctypes.c_int, [vp, c_dp, ctypes.POINTER(ctypes.c_int)]),
 }
-STAGES = ("prelude", "bands", "slots", "sensor")        # spart_profile_read_stages
+STAGES = ("prelude", "bands", "columns")        # spart_profile_read_stages
 
 _libs = {}
 

@@ -189,7 +189,7 @@ class Engine:
 
     def release_workspace(self):
         """Drop the scratch buffers the engine keeps between calls (one per stream used; each grows to the largest batch
-        seen: ~1.7 KB per sample); the next call allocates what it needs."""
+        seen: ~0.9 KB per sample); the next call allocates what it needs."""
         self._ws_buf = {}
 
     def to_f64(self, x, B=None):
@@ -494,8 +494,8 @@ class Engine:
         return ms.value, n.value
 
     def profile_read_stages(self):
-        """-> ({'prelude': ms, 'bands': ms, 'slots': ms, 'sensor': ms} summed over the timed calls, number of calls)"""
-        ms, n = (ctypes.c_double * len(_lib.STAGES))(), ctypes.c_int(0)
+        """-> ({'prelude': ms, 'bands': ms, 'columns': ms} summed over the timed calls, number of calls)"""
+        ms, n = (ctypes.c_double * 8)(), ctypes.c_int(0)      # (room for builds of earlier rounds that report four stages)
         _lib.check(self.lib, self.ctx, self.lib.spart_profile_read_stages(self.ctx, ms, ctypes.byref(n)))
         return dict(zip(_lib.STAGES, [float(x) for x in ms])), n.value
 

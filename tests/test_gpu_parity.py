@@ -332,7 +332,7 @@ def test_float32_tolerance_at_size(kind, sensor, torch_mod):
 
 def test_float32_columns_are_the_float64_columns_rounded(golden, torch_mod):
     """The default float32 mode takes its sensor columns from a float64 evaluation of the sensor-slot bands over the
-    float64 prelude (k_slots<double>): on every sensor (integer and fractional band centres), with debug rsoil
+    float64 prelude (k_columns<double, float>): on every sensor (integer and fractional band centres), with debug rsoil
     and with user dry-soil spectra, they equal the float64 mode's columns converted to float32."""
     from spart_amd import get_engine, workloads
     for sensor, kind in (("Sentinel2A-MSI", "full"), ("Sentinel2B-MSI", "pro"), ("TerraAqua-MODIS", "full"),
@@ -358,7 +358,7 @@ def test_float32_columns_are_the_float64_columns_rounded(golden, torch_mod):
 
 
 def test_float64_columns_over_float32_bands(golden, torch_mod):
-    """spart_materialize.f32_bands: float64 columns bit-identical to the float64 mode's (same prelude, slot pass, SMAC),
+    """spart_materialize.f32_bands: float64 columns bit-identical to the float64 mode's (same prelude, same column kernel),
     with the all-band evaluation in float32; against the reference's golden rows; invalid combinations are refused."""
     from spart_amd import get_engine
     g = golden["e2e"]
@@ -1250,7 +1250,7 @@ def _probe_rows(B, chunk, rng):
 def test_materialised_and_user_soil_paths_at_size(oracle, tables, dtype, B, torch_mod):
     """The store path of the fused kernel at a size where every part of its sample walk is exercised -- chunks of 37
     (float32) / 33 (float64) samples per workgroup, i.e. a full 32-sample staging block + a short one, a ragged last chunk,
-    the per-sample row advance (off += pitch), the thermal-pad broadcast, the sample-major G / rsoil slots -- with all nine
+    the per-sample row advance (off += pitch), the thermal-pad broadcast, the column kernel's support points -- with all nine
     spectrum arrays + rsoil + La + band_mean requested, for the padded and the dense row pitch, without (MAT = 1) and with
     per-sample user dry-soil spectra read from HBM (MAT = 2; SoilParametersFromFile, bsm.py:42-43).  64 probe rows are
     compared (a) with the oracle (leaf / soil / canopy spectra SPART.py:427-470, bsm.py:42-43, sailh.py:222-233 + the

@@ -152,7 +152,7 @@ def test_bench_finds_its_committed_profile_numbers():
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     for dtype, kernel, ms in (("float32", "k_bands<float, 0, 1, false>", 10.2), ("float64", "k_bands<double, 0, 1, false>", 29.0)):
-        stage = {"prelude": 1.0, "bands": ms, "slots": 0.3, "sensor": 0.3}
+        stage = {"prelude": 1.0, "bands": ms, "columns": 0.5}
         r = bench.roofline(dtype, 1_000_000, 13, stage, sum(stage.values()), kernel)
         assert r["bound"] == "valu" and 0.3 < r["frac"] < 1.0
         assert 0.4 < r["issue"]["issue_frac"] < 1.0 and r["issue"]["source"].startswith("profiles/")

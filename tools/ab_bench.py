@@ -74,7 +74,7 @@ def main():
         e.profile(0)
         ser[name] = {q: v / k for q, v in st.items()}
     for n in engs:
-        print(f"{n:24s} serial slots {ser[n]['slots']:.3f} sensor {ser[n]['sensor']:.3f} | prelude min {min(pre[n]):6.3f} | band min {min(band[n]):8.3f} med {statistics.median(band[n]):8.3f} ms | "
+        print(f"{n:24s} serial columns {ser[n]['columns']:.3f} | prelude min {min(pre[n]):6.3f} | band min {min(band[n]):8.3f} med {statistics.median(band[n]):8.3f} ms | "
               f"step min {min(wall[n]):8.3f} med {statistics.median(wall[n]):8.3f} ms | dev vs first {dev[n]:.2e}", flush=True)
 
 

@@ -83,14 +83,11 @@ for dt in ("float32", "float64"):
         v["in_step"] = k != "k_econv"
         # dominant access width of each kernel's HBM streams (spart_kernels.h): the prelude reads 8 B/lane parameter
         # columns and writes 4 / 8 B/lane constant rows; the band kernel reads 128-B constant segments and writes
-        # the 4-B / 8-B per-lane band sums (+ 16-B G rows in float64 mode); the slot pass and the sensor kernel read
-        # 8 B/lane rows and write 8 B / dtype-sized columns
+        # the 4-B / 8-B per-lane band sums; the column kernel reads 8 B/lane rows and writes dtype-sized columns
         if k.startswith("k_prelude"):
             fr, fw = corr("r", 8), corr("w", 8)
         elif k.startswith("k_bands"):
             fr, fw = (corr("r", "seg") if es == 4 else corr("r", 8)), corr("w", es)
-        elif k.startswith("k_slots"):
-            fr, fw = corr("r", 8), corr("w", 8)
         else:
             fr, fw = corr("r", 8), corr("w", es)
         v["fetch_bytes"] = v.get("FETCH_SIZE_KB", 0.0) * 1024 / fr
