@@ -246,6 +246,13 @@ int spart_profile_read_stages(spart_ctx *ctx, double stage_ms[SPART_NSTAGE], int
  *     SPART_LIDF_JUMP (1)       skip ahead in the LIDF fixed-point iteration by its contraction rate (same iterate sequence end)
  *     SPART_HOTSPOT_SERIES (1)  closed-form series for the hot-spot integrals where it converges, panels elsewhere
  *     SPART_LUT_TO (8)          observation blocks per wave of the float32 LUT scan
+ *     SPART_BANDS_PINGPONG      double-buffered constant staging in the full-band kernel (default: float32 columns-only kernel)
+ *     SPART_BANDS_SUB (32)      samples per staged copy of that kernel (64 needs the double buffer)
+ *     SPART_PRELUDE_SORT (1)    deal a workgroup's 256 samples to its waves in the order of |LIDFa| + |LIDFb|
+ *     SPART_COLUMNS_WAVES (4)   occupancy the column kernel is compiled for
+ *     SPART_COLUMNS_DIRECT (1)  column kernel stores its results directly (0: through an LDS transpose)
+ *     SPART_SMAC_LIBM (1)       library exp / sqrt in the SMAC arithmetic (0: the table-driven float64 exp of the band kernels)
+ *     SPART_SMAC_SHARE_EXP (1)  SMAC's three aerosol exponentials as products of exponentials it needs anyway
  *     SPART_EXPERIMENT          1 / 2: arithmetic-only / store-only measurement variants of k_prospect (tools/prospect_split.sh).
  *                               NOT a product configuration: variant 2 does not compute leaf spectra.  Never defined by build.py.
  */

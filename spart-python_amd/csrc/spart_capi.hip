@@ -384,7 +384,7 @@ static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_
   float* cstF = (float*)(wsp + ws.cstf_off);
   double* cstD = (double*)(wsp + ws.cstd_off);
   const T* cst = sizeof(T) == 4 ? (const T*)cstF : (const T*)cstD;       // the full-band kernel's constants
-  const TG* cstG = sizeof(TG) == 4 ? (const TG*)cstF : (const TG*)cstD;  // the slot pass's constants
+  const TG* cstG = sizeof(TG) == 4 ? (const TG*)cstF : (const TG*)cstD;  // the column kernel's constants
   double* atm = (double*)(wsp + ws.atm_off);
   // ---- everything that can fail on its arguments is checked BEFORE any launch (and before the side stream is forked)
   int chunk = pick_chunk(B);
@@ -418,11 +418,11 @@ static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_
   hipEvent_t* ev = prof ? &ctx->ev[ctx->ev_used] : nullptr;
   if (prof) HIP_TRY(ctx, hipEventRecord(ev[0], st));
   const bool four = opt && opt->band_mean;     // the four band sums are only kept apart when their means are asked for
-  const bool bands = mat || full;              // the full-band kernel runs (otherwise: pruned, slot pass only)
+  const bool bands = mat || full;              // the full-band kernel runs (otherwise: pruned, column kernel only)
   {
     Range r("SPART prelude (geometry, LIDF, hot spot, soil factors)");
     // legacy float32 columns (TG = float): the fast prelude; otherwise the literal one.  cstF only when a float32
-    // full-band kernel (or the float32 slot pass) will read it.
+    // full-band kernel (or the float32 column kernel) will read it.
     rc = launch_prelude(ctx, sizeof(TG) == 4 || (opt && opt->fast_prelude), pp, PRE_ALL, B, Bp, (sizeof(TG) == 4 || (sizeof(T) == 4 && bands)) ? cstF : nullptr,
                         sizeof(TG) == 8 ? cstD : nullptr, atm, st);
   }

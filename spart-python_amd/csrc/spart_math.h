@@ -1346,15 +1346,7 @@ template <typename A, typename CF> SPART_HD SmacOut smac_band_c(const A& atm, co
   auto EXP = [](double x) { return ::exp(x); };
   auto SQRT = [](double x) { return ::sqrt(x); };
 #else
-  // (a scheduling barrier behind each exp: left free, the scheduler interleaves the thirteen independent table-exp chains
-  //  and the kernel needs 168 VGPRs instead of 128)
-  auto EXP = [](double x) {
-    const double r = Md::exp_keepnan(x);
-#if defined(__HIP_DEVICE_COMPILE__) && defined(SPART_SMAC_SCHED_BARRIER) && SPART_SMAC_SCHED_BARRIER
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-    return r;
-  };
+  auto EXP = [](double x) { return Md::exp_keepnan(x); };
   auto SQRT = [](double x) { return Md::sqrt(x); };
 #endif
   double us = atm[A_US], uv = atm[A_UV], m = atm[A_M], Peq = atm[A_PEQ], Pa = atm[A_PA];

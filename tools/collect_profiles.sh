@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collect the round's evidence on the GPU box (run through gpurun from the repo root):
-#   gpurun --timeout 1200 -- 'bash tools/collect_profiles.sh r4_a'
+#   gpurun --timeout 1200 -- 'bash tools/collect_profiles.sh r5_final'
 # Writes under gpurun_out/<tag>/ ; tools/ingest_profiles.py <tag> copies the summaries into profiles/.
 # Counter passes are their own runs (--kernel-trace + --pmc only), FETCH_SIZE and WRITE_SIZE apart (TCC slots).
 set -e -o pipefail

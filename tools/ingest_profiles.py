@@ -162,7 +162,7 @@ if c2:
                "_note": "per launch, BASELINE config 2 (tools/prospect_bench.py 10000 float64); FETCH_SIZE / WRITE_SIZE in KB as reported"},
               open(os.path.join(dst, f"{tag}_c2_counters.json"), "w"), indent=1)
 for name in ("bench.json", "c2_bench.txt", "mode_cost.txt", "lut_rate.txt", "lut_invert_rate.txt", "mat_bench.txt", "fast_prelude_dev.txt", "power_materialized.txt",
-             "power_headline.txt", "power_cap.txt"):
+             "power_headline.txt", "power_cap.txt", "parity_262144rows.json"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, f"{tag}_{name}"))
 print(json.dumps(calib, indent=1))
