@@ -27,3 +27,13 @@ leafbio = SPART.LeafBiology(Cab=rng.uniform(10, 80, B), Cca=10, Cw=0.02, Cdm=0.0
 canopy = SPART.CanopyStructure(LAI=rng.uniform(0.1, 7, B), LIDFa=-0.35, LIDFb=-0.15, q=0.05)
 res = SPART.SPART(soilpar, leafbio, canopy, atm, angles, sensor="Sentinel2A-MSI", DOY=100, dtype="float32").run()
 print(type(res).__name__, res["R_TOC"].shape, res["R_TOA"].mean(axis=0))
+
+# the model's tables are the object's public attributes, read on every run() like in the reference (SPART.py:93-95):
+# a 5 % stronger chlorophyll absorption and a Sentinel-2 band moved by 3.5 nm, no new object needed
+sp = SPART.SPART(soilpar, SPART.LeafBiology(40, 0.01, 0.02, 0, 10, 10, 1.5), SPART.CanopyStructure(3, -0.35, -0.15, 0.05), atm, angles,
+                 sensor="Sentinel2A-MSI", DOY=100)
+before = sp.run()
+sp.optipar["Kab"] *= 1.05
+sp.sensorinfo["wl_smac"] = sp.sensorinfo["wl_smac"].astype(float) + 3.5
+after = sp.run()
+print("R_TOC at the red band: %.5f -> %.5f (centre %g -> %g nm)" % (before["R_TOC"].iloc[3], after["R_TOC"].iloc[3], before.index[3], after.index[3]))
