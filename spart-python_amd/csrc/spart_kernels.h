@@ -757,7 +757,7 @@ static __global__ __launch_bounds__(256) void k_smac(const double* __restrict__ 
   int j = (int)(i - s * nb);
   double a[NATM];
 #pragma unroll
-  for (int q = 0; q < NATM; ++q) a[q] = atm[q * Bp + s];
+  for (int q = 0; q < NATM_USED; ++q) a[q] = atm[q * Bp + s];      // (the rows the prelude writes)
   SmacOut so = smac_band(a, coef + j, nb);
   out.o[0][i] = so.Ta_s; out.o[1][i] = so.Ta_o; out.o[2][i] = so.Tg; out.o[3][i] = so.Ra_dd; out.o[4][i] = so.Ra_so;
   out.o[5][i] = so.Ta_ss; out.o[6][i] = so.Ta_sd; out.o[7][i] = so.Ta_oo; out.o[8][i] = so.Ta_do;

@@ -583,10 +583,10 @@ static_assert(NCONST == 40, "constant block is 40 values");
 
 // per-sample atmosphere scalars (double), read by the sensor-band kernel
 enum AtmIdx {
-  A_US = 0, A_UV, A_M, A_PEQ, A_PA, A_AOT, A_UO3, A_UH2O, A_CKSI, A_KSID, A_LAF,
+  A_US = 0, A_UV, A_M, A_PEQ, A_PA, A_AOT, A_CKSI, A_KSID, A_LAF,
   A_LOGPEQ, A_LOGM, A_LOGO3M, A_LOGH2OM,   // ln Peq, ln m, ln(uo3 m), ln(uh2o m): x^n is evaluated as exp(n ln x)
-  A_RSV,
-  NATM  // 16
+  A_RSV,                                   // (uo3 and uh2o themselves are not kept: smac_band reads them through the two logarithms only)
+  NATM = 16
 };
 constexpr int NATM_USED = A_RSV;      // rows the prelude writes
 
@@ -1283,8 +1283,6 @@ SPART_HD void sample_prelude_to(const In& in /* in(i) = parameter i of 27, read 
   out.a(A_PEQ, peq);
   out.a(A_PA, Pa);
   out.a(A_AOT, in(22));
-  out.a(A_UO3, in(23));
-  out.a(A_UH2O, in(24));
   out.a(A_CKSI, cksi);
   out.a(A_KSID, crd * ::acos(cksi));
   out.a(A_LOGPEQ, ::log(peq));
