@@ -504,9 +504,19 @@ class SPART:
             fields += _SPECTRA
         rdry = self.soilpar.rdry if getattr(self.soilpar, "rdry_set", False) else None
         th = (self.leafbio.rho_thermal, self.leafbio.tau_thermal)
+        # the (B, nb) results share ONE device block, so that they come back in one device-to-host copy
+        import torch
+        ncol = ["R_TOC", "R_TOA", "L_TOA", "La"] + (["rsoil"] if debug else [])
+        B = max([int(np.size(c)) if not torch.is_tensor(c) else c.numel() for c in cols if c is not None] + [1])
+        if rdry is not None:
+            r0 = rdry if torch.is_tensor(rdry) else np.asarray(rdry)
+            B = max(B, 1 if (r0.ndim == 1 or (r0.ndim == 2 and r0.shape[1] == 1)) else r0.shape[0])
+        td = torch.float32 if _engine.DTYPES[self.dtype] == 0 else torch.float64
+        blk = torch.empty((len(ncol), B, eng.nb), dtype=td, device=eng.device)
         res = eng.run(cols, self.dtype, rho_thermal=th[0], tau_thermal=th[1], materialize=fields, rdry=rdry,
-                      prune=not materialize)
-        out = {k: _np(v) for k, v in res.items()}
+                      prune=not materialize, out={k: blk[i] for i, k in enumerate(ncol)})
+        host = _np(blk)
+        out = {k: (host[ncol.index(k)] if k in ncol else _np(v)) for k, v in res.items()}
         scalar = _is_scalar(*[c for c in cols if c is not None]) and out["R_TOC"].shape[0] == 1
         wl = self.sensorinfo["wl_smac"].T[0]
         bands = self.sensorinfo["band_id_smac"]

@@ -205,10 +205,28 @@ class Engine:
         return x.contiguous()
 
     def columns(self, cols):
-        """list of per-parameter values -> (list of (B,) tensors, B)"""
-        sizes = [int(np.size(c)) if not self.torch.is_tensor(c) else c.numel() for c in cols]
+        """list of per-parameter values -> (list of (B,) tensors, B).  Host values (scalars, sequences, numpy arrays) travel in
+        ONE host-to-device copy of an (n, B) block (a scalar SPART.run() used to issue 29 one-element copies: half its
+        0.9 ms); device tensors are used where they are."""
+        torch = self.torch
+        sizes = [int(np.size(c)) if not torch.is_tensor(c) else c.numel() for c in cols]
         B = max(sizes) if sizes else 1
-        return [self.to_f64(c, B) for c in cols], B
+        host = [i for i, c in enumerate(cols) if not torch.is_tensor(c)]
+        out = [None] * len(cols)
+        if host:
+            blk = np.empty((len(host), B), dtype=np.float64)
+            for k, i in enumerate(host):
+                a = np.asarray(cols[i], dtype=np.float64).reshape(-1)
+                if a.size != B and a.size != 1:
+                    raise ValueError(f"parameter of length {a.size} does not broadcast to batch {B}")
+                blk[k] = a
+            dev = torch.as_tensor(blk).to(self.device)
+            for k, i in enumerate(host):
+                out[i] = dev[k]
+        for i, c in enumerate(cols):
+            if out[i] is None:
+                out[i] = self.to_f64(c, B)
+        return out, B
 
     def _ptrs(self, tensors):
         arr = (_lib.vp * len(tensors))(*[t.data_ptr() if t is not None else None for t in tensors])
