@@ -100,7 +100,7 @@ __device__ __forceinline__ void stage_put(T* lds_c, const T (&r)[NCONST * SUB / 
 // FAST: Newton LIDF + 8-point hot-spot panels (~1e-7 from the literal forms; only the legacy float32-columns mode),
 // otherwise the reference's own LIDF iteration and 16-point panels.  The constants are computed in float64 and
 // written in float32 (cstF, for the float32 band kernels) and / or float64 (cstD: float64 band kernels and the
-// float64 sensor-slot pass of the default float32 mode).
+// float64 column kernel of the default float32 mode).
 struct PreludeStore {            // sample_prelude_to's sink: straight to the structure-of-arrays workspace
   float* cstF;
   double* cstD;

@@ -38,11 +38,14 @@
 // blocks get no s_cbranch_execz from the compiler and cost their full issue slots)
 // SPART_KEEP_BRANCH(x), placed inside such a block, stops the compiler from if-converting it back into
 // unconditional arithmetic + select (an empty, non-speculatable asm that "touches" x).
+// SPART_WAVE_ALL(c): the condition holds in every ACTIVE lane of the wave (device) / for this value (host).
 #if defined(__HIP_DEVICE_COMPILE__)
 #define SPART_WAVE_ANY(c) (__builtin_amdgcn_ballot_w64(c) != 0)
+#define SPART_WAVE_ALL(c) (__builtin_amdgcn_ballot_w64(c) == __builtin_amdgcn_ballot_w64(true))
 #define SPART_KEEP_BRANCH(x) asm volatile("" : "+v"(x))
 #else
 #define SPART_WAVE_ANY(c) (c)
+#define SPART_WAVE_ALL(c) (c)
 #define SPART_KEEP_BRANCH(x) ((void)0)
 #endif
 
@@ -863,6 +866,31 @@ SPART_HD void lidf_sincos(double u, double s2, double c2, double& sn, double& cs
   sn = s2 * cu + c2 * su;
   cs = c2 * cu - s2 * su;
 }
+// (sn, cs) = (sin, cos)(x) -> (sin, cos)(x + d) for a SMALL step |d| <= 1/16: the angle-addition formulas with the Taylor
+// polynomials of sin d (to d^9) and 1 - cos d (to d^8) -- truncation 2e-20 / 3e-19 --, 16 multiply-adds instead of the 26 of
+// lidf_sincos.  The fixed-point iteration moves by ever smaller steps, so after its first two or three passes every pass
+// (and every Newton step of the jump) can take this form; each use adds ~1e-16 of rounding to (sn, cs), so the callers
+// re-anchor with lidf_sincos every eighth pass.
+SPART_HD void lidf_rotate(double d, double& sn, double& cs) {
+  const double d2 = d * d;
+  double ps = 1.0 / 362880.0;
+  ps = ps * d2 - 1.0 / 5040.0;
+  ps = ps * d2 + 1.0 / 120.0;
+  ps = ps * d2 - 1.0 / 6.0;
+  const double sd = d + d * (d2 * ps);                 // sin d
+  double pc = -1.0 / 40320.0;
+  pc = pc * d2 + 1.0 / 720.0;
+  pc = pc * d2 - 1.0 / 24.0;
+  pc = pc * d2 + 0.5;
+  const double cm = d2 * pc;                           // 1 - cos d
+  const double s0 = sn, c0 = cs;
+  sn = s0 + (c0 * sd - s0 * cm);
+  cs = c0 - (s0 * sd + c0 * cm);
+}
+#ifndef SPART_LIDF_ROTATE
+#define SPART_LIDF_ROTATE 1
+#endif
+constexpr double LIDF_ROT_MAX = 0.0625;
 
 // The literal iteration (the reference's stopping rule and iterates, sailh.py:378-382) in the small unknown
 // u = x - 2 theta:   x <- x + 1/2 (y - x + 2 theta)   ==   u <- u + g(u),  g(u) = 1/2 (y(u) - u),
@@ -888,15 +916,18 @@ template <bool JUMP> SPART_HD double lidf_dcum_lit_impl(double a, double b, int 
   const double s2 = lidf_sin_2theta(i), c2 = lidf_cos_2theta(i);
   const double kjump = 5e-3 / (0.25 * (::fabs(a) + 2.0 * ::fabs(b)) + 0.02);   // 5e-3 / (bound of |y''| / 4, + margin)
   double u = 0.0, y, dx = 0.0, dprev;
+  double sn = s2, cs = c2;                 // (sin, cos)(2 theta + u), carried from pass to pass
   bool more, ready = false;
   int it = 0;
   // literal phase: a lane leaves when it has converged (the reference's test) or is close enough to jump; the lanes of
   // a wave reconverge behind the loop, so the jump below runs once per wave
   do {
-    double sn, cs;
     dprev = dx;
     u += dx;                               // (the step found in the previous pass; 0 in the first)
-    lidf_sincos(u, s2, c2, sn, cs);
+    // sin / cos at the new iterate: by rotating the previous pass's pair through the step when the step is small in every
+    // lane still iterating (wave-uniform choice: `it` is the same in all of them), from scratch otherwise and every 8th pass
+    if (SPART_LIDF_ROTATE && (it & 7) != 0 && SPART_WAVE_ALL(::fabs(dx) < LIDF_ROT_MAX)) lidf_rotate(dx, sn, cs);
+    else lidf_sincos(u, s2, c2, sn, cs);
     y = sn * (a + b * cs);
     dx = 0.5 * (y - u);
     more = ::fabs(dx) > 1e-8;              // sailh.py:382 -- y belongs to the iterate BEFORE the update
@@ -910,16 +941,21 @@ template <bool JUMP> SPART_HD double lidf_dcum_lit_impl(double a, double b, int 
   if (JUMP && more && ready) {
     // state: iterate u_m = u with g(u_m) = dx (not yet applied), previous step dprev
     using Md = Mx<double>;
-    double us = u + dx * dprev * Md::rcp(dprev - dx);   // u + dx / (1 - rho): geometric extrapolation of the fixed point
-    double sn, cs, nstep = 1.0;
+    const double d0 = dx * dprev * Md::rcp(dprev - dx);
+    double us = u + d0;                    // u + dx / (1 - rho): geometric extrapolation of the fixed point
+    double nstep = 1.0;
+    // (sn, cs) belong to the iterate u: the first Newton point is a small step away (|d0| <~ 0.06 by the readiness test), every
+    // later one a tiny one
+    if (SPART_LIDF_ROTATE && SPART_WAVE_ALL(::fabs(d0) < LIDF_ROT_MAX)) lidf_rotate(d0, sn, cs);
+    else lidf_sincos(us, s2, c2, sn, cs);
     for (int k = 0; k < 3; ++k) {          // Newton on g(u) = 0: 1e-5 -> 1e-9 -> 1e-17
-      lidf_sincos(us, s2, c2, sn, cs);
       const double f = sn * (a + b * cs) - us;                            // 2 g
       const double fp = a * cs + b * (2.0 * cs * cs - 1.0) - 1.0;         // 2 g'
       nstep = f * Md::rcp(fp);
       us -= nstep;
+      if (SPART_LIDF_ROTATE && SPART_WAVE_ALL(::fabs(nstep) < LIDF_ROT_MAX)) lidf_rotate(-nstep, sn, cs);
+      else lidf_sincos(us, s2, c2, sn, cs);
     }
-    lidf_sincos(us, s2, c2, sn, cs);
     const double s2x = 2.0 * sn * cs, c2x = 2.0 * cs * cs - 1.0;          // sin 2x, cos 2x at the fixed point
     const double y1 = a * cs + b * c2x, y2 = -a * sn - 2.0 * b * s2x, y3 = -a * cs - 4.0 * b * c2x, y4 = a * sn + 8.0 * b * s2x;
     const double r = 0.5 * (1.0 + y1), q2 = 0.25 * y2, q3 = y3 * (1.0 / 12.0), q4 = y4 * (1.0 / 48.0);
@@ -962,7 +998,6 @@ template <bool JUMP> SPART_HD double lidf_dcum_lit_impl(double a, double b, int 
     }
   }
   while (more && ++it < 100000) {           // lanes that did not jump: the rest of the literal iteration
-    double sn, cs;
     u += dx;
     lidf_sincos(u, s2, c2, sn, cs);
     y = sn * (a + b * cs);
