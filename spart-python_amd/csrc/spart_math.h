@@ -38,14 +38,11 @@
 // blocks get no s_cbranch_execz from the compiler and cost their full issue slots)
 // SPART_KEEP_BRANCH(x), placed inside such a block, stops the compiler from if-converting it back into
 // unconditional arithmetic + select (an empty, non-speculatable asm that "touches" x).
-// SPART_WAVE_ALL(c): the condition holds in every ACTIVE lane of the wave (device) / for this value (host).
 #if defined(__HIP_DEVICE_COMPILE__)
 #define SPART_WAVE_ANY(c) (__builtin_amdgcn_ballot_w64(c) != 0)
-#define SPART_WAVE_ALL(c) (__builtin_amdgcn_ballot_w64(c) == __builtin_amdgcn_ballot_w64(true))
 #define SPART_KEEP_BRANCH(x) asm volatile("" : "+v"(x))
 #else
 #define SPART_WAVE_ANY(c) (c)
-#define SPART_WAVE_ALL(c) (c)
 #define SPART_KEEP_BRANCH(x) ((void)0)
 #endif
 
@@ -866,19 +863,22 @@ SPART_HD void lidf_sincos(double u, double s2, double c2, double& sn, double& cs
   sn = s2 * cu + c2 * su;
   cs = c2 * cu - s2 * su;
 }
-// (sn, cs) = (sin, cos)(x) -> (sin, cos)(x + d) for a SMALL step |d| <= 1/16: the angle-addition formulas with the Taylor
-// polynomials of sin d (to d^9) and 1 - cos d (to d^8) -- truncation 2e-20 / 3e-19 --, 16 multiply-adds instead of the 26 of
-// lidf_sincos.  The fixed-point iteration moves by ever smaller steps, so after its first two or three passes every pass
-// (and every Newton step of the jump) can take this form; each use adds ~1e-16 of rounding to (sn, cs), so the callers
-// re-anchor with lidf_sincos every eighth pass.
+// (sn, cs) = (sin, cos)(x) -> (sin, cos)(x + d) for a step |d| <= 1/4: the angle-addition formulas with the Taylor
+// polynomials of sin d (to d^11) and 1 - cos d (to d^12) -- truncation 1e-17 relative / 4e-20 --, 19 multiply-adds instead of the
+// 26 of lidf_sincos.  The fixed-point iteration moves by ever smaller steps (in the usual parameter ranges every step after the
+// second is below 1/4), so nearly every pass -- and every Newton step of the jump -- can take this form; each use adds ~1e-16 of
+// rounding to (sn, cs), so the callers re-anchor with lidf_sincos every eighth pass.
 SPART_HD void lidf_rotate(double d, double& sn, double& cs) {
   const double d2 = d * d;
-  double ps = 1.0 / 362880.0;
+  double ps = -1.0 / 39916800.0;
+  ps = ps * d2 + 1.0 / 362880.0;
   ps = ps * d2 - 1.0 / 5040.0;
   ps = ps * d2 + 1.0 / 120.0;
   ps = ps * d2 - 1.0 / 6.0;
   const double sd = d + d * (d2 * ps);                 // sin d
-  double pc = -1.0 / 40320.0;
+  double pc = -1.0 / 479001600.0;
+  pc = pc * d2 + 1.0 / 3628800.0;
+  pc = pc * d2 - 1.0 / 40320.0;
   pc = pc * d2 + 1.0 / 720.0;
   pc = pc * d2 - 1.0 / 24.0;
   pc = pc * d2 + 0.5;
@@ -890,7 +890,21 @@ SPART_HD void lidf_rotate(double d, double& sn, double& cs) {
 #ifndef SPART_LIDF_ROTATE
 #define SPART_LIDF_ROTATE 1
 #endif
-constexpr double LIDF_ROT_MAX = 0.0625;
+constexpr double LIDF_ROT_MAX = 0.25;
+// (sn, cs) at the iterate u_new = u_old + d: by rotation when `rot` (this lane's own decision), by lidf_sincos otherwise.
+// Each form is issued only when some lane of the wave takes it; a lane's result never depends on its neighbours' choices.
+SPART_HD void lidf_sincos_step(bool rot, double d, double u_new, double s2, double c2, double& sn, double& cs) {
+  double sr = sn, cr = cs;
+  if (SPART_WAVE_ANY(rot)) lidf_rotate(d, sr, cr);
+  if (SPART_WAVE_ANY(!rot)) {
+    double sf, cf;
+    lidf_sincos(u_new, s2, c2, sf, cf);
+    sr = rot ? sr : sf;
+    cr = rot ? cr : cf;
+  }
+  sn = sr;
+  cs = cr;
+}
 
 // The literal iteration (the reference's stopping rule and iterates, sailh.py:378-382) in the small unknown
 // u = x - 2 theta:   x <- x + 1/2 (y - x + 2 theta)   ==   u <- u + g(u),  g(u) = 1/2 (y(u) - u),
@@ -924,10 +938,11 @@ template <bool JUMP> SPART_HD double lidf_dcum_lit_impl(double a, double b, int 
   do {
     dprev = dx;
     u += dx;                               // (the step found in the previous pass; 0 in the first)
-    // sin / cos at the new iterate: by rotating the previous pass's pair through the step when the step is small in every
-    // lane still iterating (wave-uniform choice: `it` is the same in all of them), from scratch otherwise and every 8th pass
-    if (SPART_LIDF_ROTATE && (it & 7) != 0 && SPART_WAVE_ALL(::fabs(dx) < LIDF_ROT_MAX)) lidf_rotate(dx, sn, cs);
-    else lidf_sincos(u, s2, c2, sn, cs);
+    // sin / cos at the new iterate: by rotating the previous pass's pair through the step when THIS lane's step is small, from
+    // scratch otherwise and every eighth pass.  The choice is the lane's own (a sample's result must not depend on the samples
+    // it shares a wave with); the wave only skips a form that none of its lanes takes.
+    // (pass 0 has u = 0 and dx = 0: the rotation through 0 returns the tabulated pair unchanged)
+    lidf_sincos_step(SPART_LIDF_ROTATE && (it & 7) != 7 && ::fabs(dx) < LIDF_ROT_MAX, dx, u, s2, c2, sn, cs);
     y = sn * (a + b * cs);
     dx = 0.5 * (y - u);
     more = ::fabs(dx) > 1e-8;              // sailh.py:382 -- y belongs to the iterate BEFORE the update
@@ -946,15 +961,13 @@ template <bool JUMP> SPART_HD double lidf_dcum_lit_impl(double a, double b, int 
     double nstep = 1.0;
     // (sn, cs) belong to the iterate u: the first Newton point is a small step away (|d0| <~ 0.06 by the readiness test), every
     // later one a tiny one
-    if (SPART_LIDF_ROTATE && SPART_WAVE_ALL(::fabs(d0) < LIDF_ROT_MAX)) lidf_rotate(d0, sn, cs);
-    else lidf_sincos(us, s2, c2, sn, cs);
+    lidf_sincos_step(SPART_LIDF_ROTATE && ::fabs(d0) < LIDF_ROT_MAX, d0, us, s2, c2, sn, cs);
     for (int k = 0; k < 3; ++k) {          // Newton on g(u) = 0: 1e-5 -> 1e-9 -> 1e-17
       const double f = sn * (a + b * cs) - us;                            // 2 g
       const double fp = a * cs + b * (2.0 * cs * cs - 1.0) - 1.0;         // 2 g'
       nstep = f * Md::rcp(fp);
       us -= nstep;
-      if (SPART_LIDF_ROTATE && SPART_WAVE_ALL(::fabs(nstep) < LIDF_ROT_MAX)) lidf_rotate(-nstep, sn, cs);
-      else lidf_sincos(us, s2, c2, sn, cs);
+      lidf_sincos_step(SPART_LIDF_ROTATE && ::fabs(nstep) < LIDF_ROT_MAX, -nstep, us, s2, c2, sn, cs);
     }
     const double s2x = 2.0 * sn * cs, c2x = 2.0 * cs * cs - 1.0;          // sin 2x, cos 2x at the fixed point
     const double y1 = a * cs + b * c2x, y2 = -a * sn - 2.0 * b * s2x, y3 = -a * cs - 4.0 * b * c2x, y4 = a * sn + 8.0 * b * s2x;
