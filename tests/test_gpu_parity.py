@@ -1350,3 +1350,28 @@ def test_parity_at_scale_against_the_oracle(torch_mod, tmp_path, kind, sensor):
             assert rel.max() <= tol, (name, k, float(rel.max()), int(i), int(j), Pn[i].tolist())
     for k in ("R_TOC", "R_TOA", "L_TOA"):      # f32_bands: the float64 columns themselves, not an approximation of them
         assert torch_mod.equal(cols["float64"][k], cols["f32_bands"][k])
+
+
+def test_results_do_not_depend_on_wave_mates(torch_mod):
+    """A sample's columns are a function of its own 27 parameters: the same batch twice, the batch reversed, and every
+    2048th row evaluated alone give bit-identical float64 columns.  (The prelude deals its samples to waves by a counting sort
+    whose order inside a bucket is not fixed, and several routines branch on wave-level votes -- all of them may only SKIP work
+    no lane needs, never pick the arithmetic of one lane from the data of another; round 5 had a version of the LIDF iteration
+    that did, and whose results changed from call to call in the last bits.)"""
+    from spart_amd import get_engine, workloads
+    eng = get_engine("Sentinel2A-MSI", 0)
+    B = 100_003
+    Pn = workloads.lhs_params(B, "full", seed=77)
+    P = torch_mod.as_tensor(Pn.T.copy(), device="cuda:0")
+    a = {k: v.clone() for k, v in eng.run(P, "float64").items()}
+    b = eng.run(P, "float64")
+    Pr = torch_mod.as_tensor(Pn[::-1].T.copy(), device="cuda:0")
+    c = eng.run(Pr, "float64", prune=True)
+    rows = list(range(0, B, 2048))
+    for k in ("R_TOC", "R_TOA", "L_TOA"):
+        assert torch_mod.equal(a[k], b[k]), k
+        assert torch_mod.equal(a[k], c[k].flip(0)), k
+    for r in rows[:24]:
+        one = eng.run(torch_mod.as_tensor(Pn[r:r + 1].T.copy(), device="cuda:0"), "float64")
+        for k in ("R_TOC", "R_TOA", "L_TOA"):
+            assert torch_mod.equal(one[k][0], a[k][r]), (r, k)
