@@ -260,3 +260,53 @@ def test_content_keyed_engines_are_shared_and_bounded(SP):
         o["Kab"] = op["Kab"] * (1 + 0.01 * (i + 1))
         get_engine(None, 0, optical_params=o)
     assert len(E._by_content) <= E.MAX_CONTENT_ENGINES
+
+
+@pytest.mark.gpu
+def test_synthetic_sensor_with_the_maximum_band_count(SP, oracle):
+    """A user-made sensorinfo with 64 bands (the library's maximum) stitched from four packaged sensors -- integer and
+    fractional centres, response functions of different lengths padded with NaN wavelengths / zero weights as the
+    reference's own tables are -- through SPART.run() against the oracle handed the same tables: the content-keyed
+    engine, every wave of the column kernel walking 16 bands, both interpolation cases."""
+    from spart_amd import tables as T
+    parts = [T.load_sensor_info(n) for n in ("TerraAqua-MODIS", "Sentinel3A-OLCI", "Sentinel2A-MSI", "LANDSAT8-OLI", "LANDSAT7-ETM")]
+    take, left = [], 64
+    for p in parts:
+        take.append(min(left, np.asarray(p["wl_smac"]).size))
+        left -= take[-1]
+    assert left == 0
+    nsrf = max(p["wl_srf_smac"].shape[0] for p in parts)
+    wl, ids, coef, wsrf, psrf = [], [], {n: [] for n in T.COEF_NAMES}, [], []
+    for p, k in zip(parts, take):
+        wl.append(np.asarray(p["wl_smac"], dtype=np.float64).reshape(-1)[:k])
+        ids += list(p["band_id_smac"])[:k]
+        for n in T.COEF_NAMES:
+            coef[n].append(np.asarray(p["SMAC_coef"][n], dtype=np.float64).reshape(-1)[:k])
+        pad = nsrf - p["wl_srf_smac"].shape[0]
+        wsrf.append(np.concatenate([np.asarray(p["wl_srf_smac"], dtype=np.float64)[:, :k], np.full((pad, k), np.nan)]))
+        psrf.append(np.concatenate([np.asarray(p["p_srf_smac"], dtype=np.float64)[:, :k], np.zeros((pad, k))]))
+    si = {"wl_smac": np.concatenate(wl)[:, None], "band_id_smac": ids,
+          "SMAC_coef": {n: np.concatenate(v)[None, :] for n, v in coef.items()},
+          "wl_srf_smac": np.concatenate(wsrf, axis=1), "p_srf_smac": np.concatenate(psrf, axis=1)}
+    nb = si["wl_smac"].shape[0]
+    assert nb == 64
+    from spart_amd import workloads
+    P = workloads.lhs_params(300, "full", seed=5)
+    cols = [P[:, j] for j in range(27)]
+    sp = SP.SPART(SP.SoilParameters(*cols[9:15]), SP.LeafBiology(*cols[0:7], PROT=cols[7], CBC=cols[8]), SP.CanopyStructure(*cols[15:19]),
+                  SP.AtmosphericProperties(cols[22], cols[23], cols[24], Pa=cols[25]), SP.Angles(*cols[19:22]), "Sentinel2A-MSI", 100)
+    sp.sensorinfo = si
+    with redirect_stdout(io.StringIO()):
+        res = sp.run(debug=True)
+    assert res["R_TOC"].shape == (300, 64) and list(res.bands) == ids
+    h = _Holder("Sentinel2A-MSI")
+    h.sensorinfo = si
+    ref = oracle.spart_run(P, "Sentinel2A-MSI", tables=_oracle_tables(h, "Sentinel2A-MSI"), pso="gl", full=True)
+    for k in ("R_TOC", "R_TOA", "L_TOA", "rsoil", "La"):
+        assert rel_err(res[k], ref[k]) < 1e-8, k
+    # float32 mode: the same columns rounded once
+    sp.dtype = "float32"
+    with redirect_stdout(io.StringIO()):
+        r32 = sp.run()
+    for k in ("R_TOC", "R_TOA", "L_TOA"):
+        assert np.array_equal(r32[k], res[k].astype(np.float32)), k
