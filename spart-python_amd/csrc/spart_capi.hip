@@ -184,16 +184,23 @@ int ws_release(spart_ctx* ctx, const char* base, size_t bytes, hipStream_t st, c
   for (WsUse& u : ctx->ws_uses)
     if (u.base == base && u.stream == st) slot = &u;      // same pair again: the stream orders the two uses itself
   if (!slot && ctx->ws_uses.size() >= WS_PRUNE_AT) {
+    // An event query is "potentially unsafe" under a GLOBAL-mode stream capture anywhere in the process (torch.cuda.graph's
+    // default): it would fail and invalidate that capture.  So: none at all while THIS stream is being captured, and
+    // otherwise this thread is switched to relaxed capture interaction around the queries (what PyTorch's caching allocator
+    // does around its own event queries); only events recorded outside any capture are ever queried.
+    hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+    const bool relaxed = !capturing && hipThreadExchangeStreamCaptureMode(&mode) == hipSuccess;
     for (WsUse& u : ctx->ws_uses) {
-      // (no event query while this stream is being captured: in a global-mode capture that call is itself illegal)
       bool idle = u.captured;
-      if (!idle && !capturing) {
+      if (!idle && relaxed) {
         const hipError_t q = hipEventQuery(u.done);
         if (q == hipSuccess) idle = true;
         else (void)hipGetLastError();                     // hipErrorNotReady (or anything else): treat as in flight
       }
       if (idle) { slot = &u; break; }
     }
+    if (relaxed) (void)hipThreadExchangeStreamCaptureMode(&mode);      // (back to the thread's previous mode)
+    else if (!capturing) (void)hipGetLastError();
     if (slot) slot->bytes = 0;
   }
   if (!slot) {

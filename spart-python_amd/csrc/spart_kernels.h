@@ -457,7 +457,7 @@ void k_bands(const T* __restrict__ tab, const T* __restrict__ cst, int64_t Bp, i
 // whether the full spectra are evaluated beside it in float64, in float32, or not at all (prune_unused_bands).
 //   TG: arithmetic of the canopy model (double, except spart_materialize.f32_columns); SMAC and TOC -> TOA are float64
 //   TO: dtype of the (B, nb) outputs;  TR: element type of the optional user dry-soil spectra (the call's dtype).
-// Mapping: a workgroup owns 64 consecutive samples (lane = sample); its 36 band constants and 15 atmosphere scalars
+// Mapping: a workgroup owns 64 consecutive samples (lane = sample); its 36 band constants and 13 atmosphere scalars
 // are copied into LDS once ([row][64]: lane l reads word l of a row, conflict-free) and wave w walks the sensor bands
 // j = w, w + 4, ...: the band index -- and with it the 17 table values, the 48 SMAC coefficients, the interpolation
 // support and the "is this gas absent in this band" tests -- is wave-uniform (scalar loads, scalar branches).

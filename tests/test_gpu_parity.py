@@ -1375,3 +1375,49 @@ def test_results_do_not_depend_on_wave_mates(torch_mod):
         one = eng.run(torch_mod.as_tensor(Pn[r:r + 1].T.copy(), device="cuda:0"), "float64")
         for k in ("R_TOC", "R_TOA", "L_TOA"):
             assert torch_mod.equal(one[k][0], a[k][r]), (r, k)
+
+
+def test_event_queries_do_not_break_a_capture_in_progress(torch_mod):
+    """The library looks for completed workspace records with hipEventQuery when a new (workspace, stream) pair shows up and
+    16 are remembered.  An event query is a "potentially unsafe" call under a GLOBAL-mode stream capture (torch.cuda.graph's
+    default) anywhere in the process: the library switches the calling thread to relaxed capture interaction around its
+    queries and never queries on a capturing stream.  Here: a capture is open on one stream while 20 other streams make
+    ordinary calls with new pairs (every one of them runs the query loop); the capture must survive, its replay and the
+    ordinary calls must give the serial results."""
+    from spart_amd import get_engine, workloads
+    torch = torch_mod
+    eng = get_engine("Sentinel2A-MSI", 0)
+    B = 8192
+    P = torch.as_tensor(workloads.lhs_params(B, "full", seed=31).T.copy(), device="cuda:0")
+    P2 = torch.as_tensor(workloads.lhs_params(B, "full", seed=32).T.copy(), device="cuda:0")
+    ref = {k: v.clone() for k, v in eng.run(P, "float32").items()}
+    ref2 = {k: v.clone() for k, v in eng.run(P2, "float32", prune=True).items()}
+    n = int(eng.lib.spart_workspace_bytes(eng.ctx, 1, B))
+    ws, ws2, wsg = (torch.empty(n, dtype=torch.uint8, device="cuda:0") for _ in range(3))
+    mk = lambda: {k: torch.empty((B, eng.nb), dtype=torch.float32, device="cuda:0") for k in ("R_TOC", "R_TOA", "L_TOA")}   # noqa: E731
+    out, outs2 = mk(), [mk() for _ in range(20)]
+    streams = [torch.cuda.Stream("cuda:0") for _ in range(20)]
+    for st in streams:                                   # more than 16 live records before the capture starts
+        with torch.cuda.stream(st):
+            eng.run(P2, "float32", prune=True, _workspace=ws, out=outs2[0])
+    cap = torch.cuda.Stream("cuda:0")
+    with torch.cuda.stream(cap):
+        eng.run(P, "float32", out=out, _workspace=wsg)    # (first use of the stream and of the workspace: outside the capture)
+    torch.cuda.synchronize()
+    for t in out.values():
+        t.zero_()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=cap):
+        eng.run(P, "float32", out=out, _workspace=wsg)
+        for i, st in enumerate(streams):                 # ordinary work on other streams while the capture is open
+            with torch.cuda.stream(st):
+                eng.run(P2, "float32", prune=True, _workspace=ws2, out=outs2[i])
+    torch.cuda.synchronize()
+    for i in range(20):
+        for k in ref2:
+            assert torch.equal(outs2[i][k], ref2[k]), (i, k)
+    assert not any(bool(t.any()) for t in out.values())   # (captured, not run)
+    g.replay()
+    torch.cuda.synchronize()
+    for k in ref:
+        assert torch.equal(out[k], ref[k]), k
