@@ -1421,3 +1421,42 @@ def test_event_queries_do_not_break_a_capture_in_progress(torch_mod):
     torch.cuda.synchronize()
     for k in ref:
         assert torch.equal(out[k], ref[k]), k
+    # the same from ANOTHER host thread while this one holds a capture open (each thread has its own capture-interaction mode)
+    import threading
+    ws3 = torch.empty(n, dtype=torch.uint8, device="cuda:0")
+    streams3 = [torch.cuda.Stream("cuda:0") for _ in range(20)]
+    go, done, errors = threading.Event(), threading.Event(), []
+
+    def worker():
+        try:
+            go.wait(30)
+            for i, st in enumerate(streams3):
+                with torch.cuda.stream(st):
+                    eng.run(P2, "float32", prune=True, _workspace=ws3, out=outs2[i])
+        except Exception as e:      # noqa: BLE001
+            errors.append(e)
+        finally:
+            done.set()
+
+    for o in outs2:
+        for t in o.values():
+            t.zero_()
+    th = threading.Thread(target=worker)
+    th.start()
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2, stream=cap):
+        eng.run(P, "float32", out=out, _workspace=wsg)
+        go.set()
+        assert done.wait(60)
+    th.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    for i in range(20):
+        for k in ref2:
+            assert torch.equal(outs2[i][k], ref2[k]), ("worker thread", i, k)
+    for t in out.values():
+        t.zero_()
+    g2.replay()
+    torch.cuda.synchronize()
+    for k in ref:
+        assert torch.equal(out[k], ref[k]), ("second graph", k)
