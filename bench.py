@@ -353,8 +353,20 @@ def mode_records(torch, args, dev):
     if c is not None and c.get("batch") == 1_000_000:
         per = {n: v.get("hbm_bytes", 0.0) for n, v in c["kernels"].items() if n != "k_econv" and v.get("hbm_bytes")}
         tot = sum(per.values())
+        # how close the two float64 kernels run to their instruction issue: committed VALU wave-instruction counts x the data-sheet
+        # 4 cycles (and x the 2.28 ns MEASURED for v_fma_f64 on this chip, profiles/r4_ubench_f64_issue.txt) over THIS run's
+        # HIP-event kernel times
+        issue = {}
+        for kn, stage in (("k_prelude", "prelude"), ("k_columns", "columns")):
+            kv = next((v for n, v in c["kernels"].items() if n.startswith(kn)), None)
+            ms = r["stage_ms"].get(stage)
+            if kv and kv.get("SQ_INSTS_VALU") and ms:
+                issue[stage] = {"valu_wave_insts_per_launch": kv["SQ_INSTS_VALU"], "kernel_ms": ms,
+                                "issue_frac": kv["SQ_INSTS_VALU"] * ISSUE_CYCLES["float64"] / (1024 * 2.4e9 * ms * 1e-3),
+                                "frac_of_measured_fma_f64_rate": kv["SQ_INSTS_VALU"] * 2.28e-9 / (1024 * ms * 1e-3)}
         r["roofline"] = {"bound": "valu", "note": "float64 instruction issue binds both kernels (DESIGN.md section 4); HBM traffic reported "
                                                   "because the returned columns are what a user of the drop-in receives",
+                         "issue": issue,
                          "traffic": tot, "algorithmic_bytes": ab, "ratio_to_algorithmic": tot / ab, "traffic_per_kernel": per,
                          "achieved_GBps_over_step": tot / (r["ms_per_step"] / 1e3) / 1e9, "peak_GBps": HBM_PEAK_GBS,
                          "traffic_source": source, "profiled_sources_match": fresh}
