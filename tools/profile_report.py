@@ -55,8 +55,55 @@ def power(path):
     return f"{min(w):.0f}-{max(w):.0f} W, sclk {min(c)}-{max(c)} MHz ({len(w)} samples)" if c else f"{min(w):.0f}-{max(w):.0f} W"
 
 
+R4 = {"headline": "8.87e7, 11.27 ms, frac 0.552, 2.48 GB", "returned": "6.79e8, 1.47 ms, 2.16 GB", "fp64": "4.14e7", "c3": "7.97e7 / 8.39e7", "c2": "0.152 ms",
+      "c5": "8.80e7", "mat": "5.67e7", "lut": "4.51e12", "lutgen": "6.63e7"}      # round 4's line (profiles/r4_final_bench.json), for comparison
+
+
+def summary_table(tag, d):
+    """the BASELINE-config table of DESIGN.md section 8, every figure from <tag>_bench.json"""
+    r, c, f = d["roofline"], d.get("configs") or {}, d.get("fp64") or {}
+    pr, cb = c.get("pruned", {}), d.get("cpu_baseline") or {}
+    g = lambda k: c.get(k, {})                                                    # noqa: E731
+    rows = ["| BASELINE config | value (round 5, `" + tag + "_bench.json`) | round 4 |", "|---|---|---|"]
+    rows.append(f"| 4 (headline): full SPART, B = 1M, Sentinel-2A, fp32, all 2162 bands, columns = float64 column path | **{d['value']:.3g} spectra/s** ({d['ms_per_step']:.2f} ms/step: "
+                f"`k_prelude` {r['stage_ms']['prelude']:.2f}, then `k_bands` {r['kernel_ms']:.2f} with `k_columns` beside it on the side stream); `roofline.frac` **{r['frac']:.3f}** "
+                f"(issue fraction {r.get('issue', {}).get('issue_frac', 0):.3f}); counter traffic {(r.get('traffic') or 0) / 1e9:.2f} GB per step = {r['hbm'].get('ratio_to_algorithmic', 0):.1f} x the algorithmic bytes; "
+                f"with `fast_prelude` {g('fast_prelude').get('value', 0):.3g} ({g('fast_prelude').get('ms_per_step', 0):.2f} ms) -- target was >= 1e6 | {R4['headline']} |")
+    pi = (pr.get("roofline") or {}).get("issue") or {}
+    iss = "; ".join(f"{k} {v['issue_frac']:.2f} of the 4-cycle float64 issue rate = {v['frac_of_measured_fma_f64_rate']:.2f} of the MEASURED v_fma_f64 rate" for k, v in pi.items())
+    rows.append(f"| `returned_columns` = `configs.pruned` (the SECOND headline: what the `R_TOC / R_TOA / L_TOA` a caller receives cost; `prune_unused_bands = 1`, NOT full spectra) | "
+                f"**{pr.get('value', 0):.3g} spectra/s** ({pr.get('ms_per_step', 0):.3f} ms per 1M: prelude {pr.get('stage_ms', {}).get('prelude', 0):.3f} + column kernel {pr.get('stage_ms', {}).get('columns', 0):.3f}), "
+                f"columns bit-identical to the full evaluation: {pr.get('columns_bit_identical_to_full_evaluation')}; counter traffic **{((pr.get('roofline') or {}).get('traffic') or 0) / 1e9:.2f} GB**; {iss}; "
+                f"with `fast_prelude` {(pr.get('with_fast_prelude') or {}).get('ms_per_step', 0):.3f} ms | {R4['returned']} |")
+    fr = f.get("roofline", {})
+    rows.append(f"| same as 4 in fp64 (`fp64` sub-record) | **{f.get('value', 0):.3g} spectra/s** ({f.get('ms_per_step', 0):.2f} ms; band kernel {fr.get('kernel_ms', 0):.2f} ms, `roofline.frac` {fr.get('frac', 0):.3f}); "
+                f"the same float64 columns over a float32 evaluation of the 2162 bands (`f32_bands`): the headline's rate, identical by construction | {R4['fp64']} |")
+    rows.append(f"| 3: B = 100k, Sentinel-2A, fp32 (`configs.3`, HIP-graph replays) | {g('3').get('value', 0):.3g} spectra/s ({g('3').get('ms_per_step', 0):.3f} ms); 125k (the per-GPU shard of config 4 cut in 8): "
+                f"{g('4_shard_125k').get('value', 0):.3g} ({g('4_shard_125k').get('ms_per_step', 0):.3f} ms) | {R4['c3']} |")
+    c2 = g("2")
+    rows.append(f"| 2: PROSPECT-5D leaf only, 10k x 2001, fp64 (`configs.2`) | {c2.get('ms_per_step', 0):.3f} ms per call = {c2.get('value', 0):.3g} leaf spectra/s = {(c2.get('roofline') or {}).get('achieved', 0) / 1e3:.2f} TB/s "
+                f"of the 48 096 B/spectrum (`roofline.frac` {(c2.get('roofline') or {}).get('frac', 0):.3f}); package-power-bound (section 4) | {R4['c2']} |")
+    rows.append(f"| 5: PROSPECT-PRO + SAILH, B = 1M, Sentinel-2B (`configs.5`) | {g('5').get('value', 0):.3g} spectra/s fp32 ({g('5').get('ms_per_step', 0):.2f} ms); fp32 vs fp64 max "
+                f"{max((g('5').get('fp32_vs_fp64_max_rel_floor1e-6') or {'x': 0}).values()):.3g} on the three columns (floor 1e-6) | {R4['c5']} |")
+    m = g("materialized")
+    rows.append(f"| `configs.materialized` (9 arrays, 75 KB/spectrum fp32, B = 200k, padded row pitch) | {m.get('value', 0):.3g} spectra/s ({m.get('ms_per_step', 0):.3f} ms/step; `roofline.frac` {(m.get('roofline') or {}).get('frac', 0):.3f} = "
+                f"{(m.get('roofline') or {}).get('achieved', 0) / 1e3:.2f} TB/s stored inside the band kernel); power-bound (power files below); follows the box: 5.4e7 ... 5.9e7 across the round's runs | {R4['mat']} |")
+    li = g("lut_invert")
+    rows.append(f"| `configs.lut_invert` (1M-row LUT x 65 536 observations, fp32) | {li.get('value', 0):.3g} row comparisons/s ({li.get('ms_per_step', 0):.2f} ms), {li.get('winners_equal_to_brute_force')} / {li.get('checked', 65536)} winners and "
+                f"{li.get('costs_bit_equal')} costs bit-equal to the brute force, `roofline.frac` {(li.get('roofline') or {}).get('frac', 0):.3f} of the MFMA peak, {li.get('observations_on_the_brute_force_path')} observations on the brute-force path | {R4['lut']} |")
+    rows.append(f"| `configs.lut_generate` (host table in, host columns out, 8M spectra) | {g('lut_generate').get('value', 0):.3g} spectra/s with all bands evaluated ({g('lut_generate').get('ms_per_step', 0):.0f} ms) | {R4['lutgen']} |")
+    rr, ric = cb.get("reference_route", {}), cb.get("reference_in_container", {})
+    rows.append(f"| CPU, three figures side by side (`cpu_baseline`) | the reference itself, build container: {ric.get('value')} {ric.get('unit')} (`reference_in_container`, a stated constant: the reference cannot travel); "
+                f"the oracle on the reference's own QUADPACK route, ONE ROW PER CALL, GPU-box host: {rr.get('per_core', 0):.2g} per core, {rr.get('value', 0):.3g} on {rr.get('cores')} cores (`reference_route`); "
+                f"the vectorised port (closed forms, 256-row blocks): {cb.get('per_core', 0):.3g} per core, {cb.get('value', 0):.3g} on {cb.get('cores')} cores (`value`) | -- |")
+    return rows
+
+
 def block(tag, prefix):
     L = [f"_Generated by `python tools/profile_report.py {tag} {prefix}` from the files named; do not edit by hand._", ""]
+    bp0 = os.path.join(PROF, f"{tag}_bench.json")
+    if os.path.exists(bp0):
+        L += summary_table(tag, json.loads(open(bp0).read().strip().splitlines()[-1])) + [""]
     bp = os.path.join(PROF, f"{tag}_bench.json")
     if os.path.exists(bp):
         d = json.loads(open(bp).read().strip().splitlines()[-1])
