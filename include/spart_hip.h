@@ -114,8 +114,8 @@ typedef struct spart_materialize {
   int32_t fast_prelude;        /* 0 (default): the reference's own LIDF fixed-point iteration with its |dx| <= 1e-8 stopping rule
                                   (sailh.py:378-382) and 10-point hot-spot panels -- the columns agree with the reference to
                                   ~1e-11.  1: the ROOT of the same equation by Newton (the reference stops up to ~5e-8 short
-                                  of it) and 8-point panels; the per-sample prelude kernel takes half the time (0.93 -> 0.45 ms
-                                  per 1M spectra).  It is a different function at the 1e-8 level.  Measured over all 2 x 13M
+                                  of it) and 8-point panels; the per-sample prelude kernel takes 0.41 instead of 0.69 ms
+                                  per 1M spectra (round 5; 0.45 / 0.93 when this option was introduced).  It is a different function at the 1e-8 level.  Measured over all 2 x 13M
                                   float64 column entries of BASELINE configs 4 and 5 (1M rows each; bench.py
                                   configs.fast_prelude.float64_columns_vs_default and test_fast_prelude_at_size repeat the
                                   measurement): on SURVEY 8(d)'s metric |d| / max(|ref|, 1e-6) the median is 2.5e-10, 99.999 % of

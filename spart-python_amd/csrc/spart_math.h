@@ -928,7 +928,10 @@ template <bool JUMP> SPART_HD double lidf_dcum_lit_impl(double a, double b, int 
   const double rd = PI / 180.0;
   const double theta2 = 2.0 * rd * lidf_theta(i);
   const double s2 = lidf_sin_2theta(i), c2 = lidf_cos_2theta(i);
-  const double kjump = 5e-3 / (0.25 * (::fabs(a) + 2.0 * ::fabs(b)) + 0.02);   // 5e-3 / (bound of |y''| / 4, + margin)
+#ifndef SPART_LIDF_KJUMP
+#define SPART_LIDF_KJUMP 2e-2   // (5e-3 until round 5: same iterates -- 0 mismatches in 5.4M solves against the literal loop -- two passes fewer)
+#endif
+  const double kjump = SPART_LIDF_KJUMP / (0.25 * (::fabs(a) + 2.0 * ::fabs(b)) + 0.02);   // 5e-3 / (bound of |y''| / 4, + margin)
   double u = 0.0, y, dx = 0.0, dprev;
   double sn = s2, cs = c2;                 // (sin, cos)(2 theta + u), carried from pass to pass
   bool more, ready = false;
@@ -946,7 +949,10 @@ template <bool JUMP> SPART_HD double lidf_dcum_lit_impl(double a, double b, int 
     y = sn * (a + b * cs);
     dx = 0.5 * (y - u);
     more = ::fabs(dx) > 1e-8;              // sailh.py:382 -- y belongs to the iterate BEFORE the update
-    if (JUMP && ::fabs(dx) < 4e-3) {
+#ifndef SPART_LIDF_GATE
+#define SPART_LIDF_GATE 1e-2    // (4e-3 until round 5)
+#endif
+    if (JUMP && ::fabs(dx) < SPART_LIDF_GATE) {
       // rho = dx / dprev estimates r; ready when 0.3 < rho < 0.98 and |dx| < 5e-3 rho (1 - rho)^2 / c2max, written
       // without the division: |dprev|^3 < K (|dprev| - |dx|)^2
       const double ad = ::fabs(dx), ap = ::fabs(dprev), df = ap - ad;
