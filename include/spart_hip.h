@@ -245,6 +245,7 @@ int spart_profile_read_stages(spart_ctx *ctx, double stage_ms[SPART_NSTAGE], int
  *     SPART_FRESH_COEF (1)      re-materialise the plate-model polynomial coefficients per use instead of holding them in VGPRs
  *     SPART_LIDF_JUMP (1)       skip ahead in the LIDF fixed-point iteration by its contraction rate (same iterate sequence end)
  *     SPART_LIDF_ROTATE (1)     sin / cos of an LIDF iterate by rotating the previous iterate's pair through the (small) step
+ *     SPART_LIDF_KJUMP (2e-2), SPART_LIDF_GATE (1e-2)   how early that skip takes over from the literal passes (expansion parameter, step size)
  *     SPART_HOTSPOT_SERIES (1)  closed-form series for the hot-spot integrals where it converges, panels elsewhere
  *     SPART_LUT_TO (8)          observation blocks per wave of the float32 LUT scan
  *     SPART_BANDS_PINGPONG      double-buffered constant staging in the full-band kernel (default: float32 columns-only kernel)
