@@ -1072,7 +1072,9 @@ SPART_HD void volscatt1(double sin_tts, double cos_tts, double sin_tto, double c
   double As = ::fmax(Ss, Cs), Ao = ::fmax(So, Co);
   double cbs = -Cs / As, cbo = -Co / Ao;                         // cos bts, cos bto
   double bts = ::acos(cbs), bto = ::acos(cbo);
-  double sbs = ::sqrt(::fmax(0.0, 1.0 - cbs * cbs)), sbo = ::sqrt(::fmax(0.0, 1.0 - cbo * cbo));
+  using Md = Mx<double>;           // (device: v_rsq_f64 + one Newton step, 1e-15; the two divisions above stay IEEE: -Cs / As must be
+                                   //  EXACTLY -1 when As = Cs, acos magnifies anything less near +-1)
+  double sbs = Md::sqrt(::fmax(0.0, 1.0 - cbs * cbs)), sbo = Md::sqrt(::fmax(0.0, 1.0 - cbo * cbo));
   chi_o = 2.0 / PI * ((bto - PI / 2) * Co + sbo * So);
   chi_s = 2.0 / PI * ((bts - PI / 2) * Cs + sbs * Ss);
   double delta1 = ::fabs(bts - bto);
@@ -1089,8 +1091,9 @@ SPART_HD void volscatt1(double sin_tts, double cos_tts, double sin_tto, double c
   double T2 = sbt2 * (2.0 * As * Ao + Ss * So * cbt1 * cbt3);
   double Jmin = bt2 * T1 - T2;
   double Jplus = (PI - bt2) * T1 + T2;
-  frho = ::fmax(0.0, Jplus / (2.0 * PI * PI));
-  ftau = ::fmax(0.0, -Jmin / (2.0 * PI * PI));
+  constexpr double I2PI2 = 1.0 / (2.0 * PI * PI);                 // (a multiplication: <= 1 ulp from the reference's division)
+  frho = ::fmax(0.0, Jplus * I2PI2);
+  ftau = ::fmax(0.0, -Jmin * I2PI2);
 }
 
 // Hot-spot integrals (sailh.py:115-135, 216, 219).  The reference integrates Psofunction over
@@ -1148,11 +1151,16 @@ template <bool FAST> SPART_HD double gl_panel(const PsoFn& f, double a, double b
 SPART_HD double hotspot_g1(double a, double x) {
   using Md = Mx<double>;
   double t = Md::rcp(a * (a + 1.0)), s = t, d = a + 1.0;
-  for (int n = 2; n < 200; ++n) {
-    d += 1.0;
-    t *= x * Md::rcp(d);
-    s += t;
-    if (!(t > 1e-17 * s)) break;          // (also ends on NaN)
+  for (int n = 2; n < 200; n += 2) {      // two terms per pass: both divisions from ONE reciprocal of the product
+    const double d1 = d + 1.0, d2 = d + 2.0;
+    const double r = Md::rcp(d1 * d2);
+    const double t1 = (t * x) * (d2 * r);   // t x / d1
+    const double t2 = (t1 * x) * (d1 * r);  // t1 x / d2
+    s += t1;
+    s += t2;
+    t = t2;
+    d = d2;
+    if (!(t2 > 1e-17 * s)) break;         // (also ends on NaN; at most one term beyond the old stopping point)
   }
   return s;
 }
