@@ -1,4 +1,4 @@
-"""Step time of spart_run_batch per mode on one GPU: float32 default (float64 sensor-slot pass), float32 legacy columns
+"""Step time of spart_run_batch per mode on one GPU: float32 default (float64 column kernel), float32 legacy columns
 (f32_columns), float64; B = 1M and 100k.  Run under `rocprofv3 --kernel-trace --stats` for the per-kernel split."""
 import os
 import sys

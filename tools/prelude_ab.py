@@ -1,4 +1,4 @@
-"""Per-stage times of the pruned step (prelude + slot pass + sensor kernel) for several library builds.
+"""Per-stage times of the pruned step (prelude + column kernel) for several library builds.
 
     python tools/prelude_ab.py name=path.so ...   [--batch N]"""
 import os
