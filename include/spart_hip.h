@@ -49,6 +49,15 @@ extern "C" {
 #define SPART_NPARAM 27     /* parameter columns of spart_run_batch         */
 #define SPART_NCOEF 48      /* SMAC coefficient rows    (smac.py:44-92)     */
 
+#define SPART_NLAYERS 60    /* canopy layers, CanopyStructure's default (sailh.py:345) */
+#define SPART_MAX_NLAYERS 1000000
+
+/* Version of THIS interface (struct layouts, argument lists, stage count): spart_abi_version() of a loaded library must
+ * equal the header's a binding was written against (the Python loader checks, so that a library built from another
+ * round's header -- e.g. through SPART_HIP_LIB -- is refused instead of being called with shifted arguments).
+ *   6: spart_materialize.lidf_in / .nlayers, spart_sailh_batch(lidf_in, nlayers), spart_abi_version itself */
+#define SPART_ABI_VERSION 6
+
 #define SPART_F32 0
 #define SPART_F64 1
 
@@ -124,6 +133,14 @@ typedef struct spart_materialize {
                                   below 1e-3 (strongly absorbing bands, |d| < 1e-9).  So: inside the float32 contract (1e-4)
                                   everywhere, inside the float64 contract (1e-6) wherever the value is at least 1e-3.
                                   Implied by f32_columns */
+  const double *lidf_in;       /* INPUT, optional: (B,13) float64 row-major, the leaf inclination distribution the reference's
+                                  SAILH reads from canopy.lidf at call time (sailh.py:51 -> k, K, bf, sob, sof at :93-97).  NULL
+                                  (default): derived from params[16..17] = LIDFa, LIDFb exactly as CanopyStructure's constructor
+                                  does (sailh.py:348, 351-398).  Given: used as it is (no normalisation, like the reference's
+                                  dot products), LIDFa / LIDFb are not read and may be NULL */
+  int32_t nlayers;             /* canopy.nlayers (sailh.py:48): 0 = the default 60.  It enters the model only as dx = 1 / nlayers,
+                                  the width of the stretch below the canopy that Pso[nlayers] averages (:131-135, 219); one value
+                                  per call.  1 ... SPART_MAX_NLAYERS */
 } spart_materialize;
 
 int spart_ctx_create(spart_ctx **out, int device, const spart_tables *tables);
@@ -134,6 +151,7 @@ const char *spart_last_error(const spart_ctx *ctx); /* text of the last error ra
  * from (spart-python_amd/build.py: source_id).  The Python loader refuses a library whose id is not that of the
  * sources next to it, and bench.py prints it, so a stale .so cannot be measured silently.  No reference counterpart. */
 const char *spart_build_id(void);
+int spart_abi_version(void);                              /* SPART_ABI_VERSION the library was compiled with */
 
 int spart_ctx_nb(const spart_ctx *ctx);                    /* sensor bands of the context */
 int spart_ctx_econv(const spart_ctx *ctx, double *host_out); /* (nb,) SRF-convolved ET irradiance (SPART.py:389-394), copied to HOST */
@@ -172,10 +190,13 @@ int spart_bsm_batch(spart_ctx *ctx, int dtype, int64_t B, const double *const so
 int spart_lidf_batch(spart_ctx *ctx, int64_t B, const double *LIDFa, const double *LIDFb, double *lidf, void *stream);
 
 /* SAILH (sailh.py:14-237).  rho, tau, rs: (B,2162) in `dtype`; canopy[4] = LAI, LIDFa, LIDFb, q;
- * angles[3] = sol, obs, rel (degrees).  out4 = rso, rdo, rsd, rdd, each (B,2162). */
+ * angles[3] = sol, obs, rel (degrees).  out4 = rso, rdo, rsd, rdd, each (B,2162).
+ * lidf_in, nlayers: the two attributes SAILH reads from the canopy OBJECT (sailh.py:48, 51), with the meaning of the
+ * spart_materialize members of the same names: lidf_in optional (B,13) float64 (NULL: from LIDFa / LIDFb; given: canopy[1],
+ * canopy[2] may be NULL), nlayers 0 = 60. */
 int spart_sailh_batch(spart_ctx *ctx, int dtype, int64_t B, const void *rho, const void *tau, const void *rs,
-                      const double *const canopy[4], const double *const angles[3], void *const out4[4],
-                      void *workspace, size_t workspace_bytes, void *stream);
+                      const double *const canopy[4], const double *const angles[3], const double *lidf_in, int32_t nlayers,
+                      void *const out4[4], void *workspace, size_t workspace_bytes, void *stream);
 
 /* SMAC (smac.py:14-213).  angles[3]; atm[4] = aot550, uo3, uh2o, Pa.  out9 (B,nb) float64 in the
  * AtmosphericOptics order Ta_s, Ta_o, Tg, Ra_dd, Ra_so, Ta_ss, Ta_sd, Ta_oo, Ta_do (smac.py:209-211). */

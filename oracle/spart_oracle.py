@@ -287,17 +287,18 @@ def _pso_function(x, K, k, LAI, q, dso):
     return np.exp((K + k) * LAI * x - np.sqrt(K * k) * LAI * x)
 
 
-def _pso_quad(K, k, LAI, q, dso):
-    """61 layer integrals by scipy quad, literally sailh.py:131-135.  returns (B, 61)."""
+def _pso_quad(K, k, LAI, q, dso, nl=NL):
+    """nl + 1 layer integrals by scipy quad, literally sailh.py:131-135 (nl = canopy.nlayers, :48).  returns (B, nl + 1)
+    (np.arange may give xl one point more than nl + 1, :52; the reference only reads Pso[0:nl] and Pso[nl], :216, 219)."""
     import scipy.integrate as integrate
 
     B = K.shape[0]
-    dx = 1 / NL
-    xl = np.arange(0, -1 - (1 / NL), -1 / NL)       # sailh.py:52
-    Pso = np.zeros((B, NL + 1))
+    dx = 1 / nl
+    xl = np.arange(0, -1 - (1 / nl), -1 / nl)       # sailh.py:52
+    Pso = np.zeros((B, nl + 1))
     for i in range(B):
         args = (float(K[i]), float(k[i]), float(LAI[i]), float(q[i]), float(dso[i]))
-        for j in range(NL + 1):
+        for j in range(nl + 1):
             Pso[i, j] = integrate.quad(_pso_function, xl[j] - dx, xl[j], args=args)[0] / dx
     return Pso
 
@@ -305,14 +306,14 @@ def _pso_quad(K, k, LAI, q, dso):
 _GL_X, _GL_W = np.polynomial.legendre.leggauss(20)
 
 
-def _pso_gl(K, k, LAI, q, dso):
-    """Vectorised alternative: returns (sum_{j<60} Pso_j, Pso_60) from graded Gauss-Legendre panels.
+def _pso_gl(K, k, LAI, q, dso, nl=NL):
+    """Vectorised alternative: returns (sum_{j<nl} Pso_j, Pso_nl) from graded Gauss-Legendre panels.
 
-    sum_j Pso_j * dx == integral over [-1, 0]; Pso_60 * dx == integral over [-1-dx, -1]
+    sum_j Pso_j * dx == integral over [-1, 0]; Pso_nl * dx == integral over [-1-dx, -1]
     (sailh.py:131-135, 216, 219).  Panels halve towards x = 0 where the integrand varies on
     the scale 1/alpha.
     """
-    dx = 1 / NL
+    dx = 1 / nl
     A = (K + k) * LAI
     with np.errstate(all="ignore"):
         alpha = np.where(dso != 0, (dso / q) * 2 / (k + K), 1.0)
@@ -343,17 +344,22 @@ def _pso_gl(K, k, LAI, q, dso):
         total = total + panel(lo, lo / 2)
         lo = lo / 2
     total = total + panel(lo, 0.0)
-    below = panel(-1.0 - dx, -1.0 - dx / 2) + panel(-1.0 - dx / 2, -1.0)
+    npan = max(2, 2 * int(math.ceil(NL / nl)))      # (panels no wider than 1/120, as for the default 60 layers)
+    h = dx / npan
+    below = sum(panel(-1.0 - (i + 1) * h, -1.0 - i * h) for i in range(npan))
     return total / dx, below / dx
 
 
-def sailh(rho, tau, rs, canopy, angles, pso="quad", lidf=None):
+def sailh(rho, tau, rs, canopy, angles, pso="quad", lidf=None, nlayers=NL):
     """SAILH, sailh.py:14-237.
 
     rho, tau, rs : (B, 2162) leaf reflectance / transmittance, soil reflectance (thermal padded)
     canopy : (B, 4) [LAI, LIDFa, LIDFb, q];  angles : (B, 3) [tts, tto, psi]
+    lidf : canopy.lidf as SAILH reads it from the object (sailh.py:51), (13,), (13, 1) or (B, 13); None = the constructor's
+           calculate_leafangles(LIDFa, LIDFb) (sailh.py:348).  nlayers : canopy.nlayers (sailh.py:48)
     returns dict rso, rdo, rsd, rdd (B, 2162) and the sample scalars in 'aux'
     """
+    NL = int(nlayers)                                   # (shadows the module default below: sailh.py:48, 52-54)
     rho = np.atleast_2d(rho)
     tau = np.atleast_2d(tau)
     rs = np.atleast_2d(rs)
@@ -365,6 +371,9 @@ def sailh(rho, tau, rs, canopy, angles, pso="quad", lidf=None):
     q = canopy[:, 3:4]
     if lidf is None:
         lidf = calculate_leafangles(canopy[:, 1], canopy[:, 2])     # sailh.py:348
+    else:
+        lidf = np.asarray(lidf, dtype=np.float64)
+        lidf = lidf.reshape(1, 13) if lidf.size == 13 else lidf       # (13,) / (13, 1) -> one row, broadcast over the batch
     deg2rad = np.pi / 180
     litab = np.array([*range(5, 80, 10), *range(81, 91, 2)], dtype=np.float64)[None, :]   # :49
     dx = 1 / NL
@@ -393,11 +402,11 @@ def sailh(rho, tau, rs, canopy, angles, pso="quad", lidf=None):
 
         # hot spot, :115-135 (Ps/Po of :108-113 are dead code)
         if pso == "quad":
-            Pso = _pso_quad(K[:, 0], k[:, 0], LAI[:, 0], q[:, 0], dso[:, 0])
+            Pso = _pso_quad(K[:, 0], k[:, 0], LAI[:, 0], q[:, 0], dso[:, 0], NL)
             sumPso = np.sum(Pso[:, 0:NL], axis=1, keepdims=True)
             Pso2w = Pso[:, NL:NL + 1]
         else:
-            s, b2 = _pso_gl(K[:, 0], k[:, 0], LAI[:, 0], q[:, 0], dso[:, 0])
+            s, b2 = _pso_gl(K[:, 0], k[:, 0], LAI[:, 0], q[:, 0], dso[:, 0], NL)
             sumPso, Pso2w = s[:, None], b2[:, None]
 
         sigb = ddb * rho + ddf * tau                                   # :142-152
@@ -622,7 +631,7 @@ def pad_soil(refl):
 
 
 def spart_run(P, sensor, tables=None, e1="exp1", pso="quad",
-              rho_thermal=0.01, tau_thermal=0.01, full=False, rdry=None):
+              rho_thermal=0.01, tau_thermal=0.01, full=False, rdry=None, lidf=None, nlayers=NL):
     """SPART(...).run() for a fresh object per row (SPART.py:162-269).
 
     P : (B, 27) parameter matrix (layout in the module docstring)
@@ -637,7 +646,7 @@ def spart_run(P, sensor, tables=None, e1="exp1", pso="quad",
     rwet, rdry = bsm(soil, tables, rdry=rdry)      # rdry given: SoilParametersFromFile branch (bsm.py:42-43)
     rho, tau = pad_leaf(refl, tran, rho_thermal, tau_thermal)
     rs = pad_soil(rwet)
-    can = sailh(rho, tau, rs, canopy, angles, pso=pso)
+    can = sailh(rho, tau, rs, canopy, angles, pso=pso, lidf=lidf, nlayers=nlayers)   # canopy.lidf / .nlayers (sailh.py:48, 51)
     i0, i1, fr = interp_weights(sens["wl_smac"])
     lerp = lambda y: y[:, i0] + (y[:, i1] - y[:, i0]) * fr[None, :]
     rv_so, rv_do, rv_dd, rv_sd = lerp(can["rso"]), lerp(can["rdo"]), lerp(can["rdd"]), lerp(can["rsd"])

@@ -287,7 +287,13 @@ template <typename T> int upload(const spart_ctx* ctx, T** dst, const std::vecto
 int launch_prelude(spart_ctx* ctx, bool fast, const ParamPtrs& pp, int mask, int64_t B, int64_t Bp, float* cstF,
                    double* cstD, double* atm, hipStream_t st) {
   unsigned grid = (unsigned)((B + 255) / 256);
-  if (fast) hipLaunchKernelGGL((k_prelude<true>), dim3(grid), dim3(256), 0, st, pp, mask, B, Bp, cstF, cstD, atm);
+  const bool user = pp.lidf != nullptr || (pp.nlayers > 0 && pp.nlayers != NLAYER);   // canopy state of the caller's own
+  if (user) {
+    ParamPtrs pu = pp;
+    if (pu.nlayers <= 0) pu.nlayers = NLAYER;
+    if (fast) hipLaunchKernelGGL((k_prelude<true, true>), dim3(grid), dim3(256), 0, st, pu, mask, B, Bp, cstF, cstD, atm);
+    else hipLaunchKernelGGL((k_prelude<false, true>), dim3(grid), dim3(256), 0, st, pu, mask, B, Bp, cstF, cstD, atm);
+  } else if (fast) hipLaunchKernelGGL((k_prelude<true>), dim3(grid), dim3(256), 0, st, pp, mask, B, Bp, cstF, cstD, atm);
   else hipLaunchKernelGGL((k_prelude<false>), dim3(grid), dim3(256), 0, st, pp, mask, B, Bp, cstF, cstD, atm);
   HIP_TRY(ctx, hipGetLastError());
   return SPART_OK;
@@ -351,12 +357,14 @@ static int bsm_impl(spart_ctx* ctx, int64_t B, const double* const soil[6], cons
 
 template <typename T>
 static int sailh_impl(spart_ctx* ctx, int64_t B, const void* rho, const void* tau, const void* rs,
-                      const double* const canopy[4], const double* const angles[3], void* const out4[4], char* wsp,
-                      const Workspace& ws, hipStream_t st) {
+                      const double* const canopy[4], const double* const angles[3], const double* lidf_in, int nlayers,
+                      void* const out4[4], char* wsp, const Workspace& ws, hipStream_t st) {
   ParamPtrs pp;
   std::memset(&pp, 0, sizeof(pp));
   for (int i = 0; i < 4; ++i) pp.p[15 + i] = canopy[i];
   for (int i = 0; i < 3; ++i) pp.p[19 + i] = angles[i];
+  pp.lidf = lidf_in;
+  pp.nlayers = nlayers;
   T* cst = stage_cst<T>(wsp, ws);
   int rc = launch_stage_prelude<T>(ctx, pp, PRE_CANOPY, B, wsp, ws, st);
   if (rc) return rc;
@@ -387,6 +395,8 @@ static int run_impl(spart_ctx* ctx, int64_t B, const double* const params[SPART_
   for (int i = 0; i < NPARAM; ++i) pp.p[i] = params[i];
   pp.rho_th = rho_th;
   pp.tau_th = tau_th;
+  pp.lidf = opt ? opt->lidf_in : nullptr;        // canopy.lidf / canopy.nlayers as the caller set them (sailh.py:48, 51)
+  pp.nlayers = opt ? opt->nlayers : 0;
   const int64_t Bp = ws.Bp;
   float* cstF = (float*)(wsp + ws.cstf_off);
   double* cstD = (double*)(wsp + ws.cstd_off);
@@ -661,6 +671,8 @@ extern "C" {
 
 const char* spart_build_id(void) { return k_build_id + 15; }
 
+int spart_abi_version(void) { return SPART_ABI_VERSION; }
+
 const char* spart_last_error(const spart_ctx*) { return g_err; }
 
 int spart_ctx_nb(const spart_ctx* ctx) { return ctx ? ctx->nb : 0; }
@@ -916,17 +928,19 @@ int spart_lidf_batch(spart_ctx* ctx, int64_t B, const double* LIDFa, const doubl
 
 
 int spart_sailh_batch(spart_ctx* ctx, int dtype, int64_t B, const void* rho, const void* tau, const void* rs,
-                      const double* const canopy[4], const double* const angles[3], void* const out4[4],
-                      void* workspace, size_t workspace_bytes, void* stream) {
+                      const double* const canopy[4], const double* const angles[3], const double* lidf_in, int32_t nlayers,
+                      void* const out4[4], void* workspace, size_t workspace_bytes, void* stream) {
   CHECK_COMMON("spart_sailh_batch")
   if (!rho || !tau || !rs || !canopy || !angles || !out4) return fail(ctx, SPART_ERR_INVALID, "spart_sailh_batch: null argument");
+  if (nlayers < 0 || nlayers > SPART_MAX_NLAYERS) return fail(ctx, SPART_ERR_INVALID, "spart_sailh_batch: nlayers = %d (0 = the default 60, else 1 ... %d)", nlayers, SPART_MAX_NLAYERS);
   for (int i = 0; i < 4; ++i)
-    if (!canopy[i] || !out4[i]) return fail(ctx, SPART_ERR_INVALID, "spart_sailh_batch: canopy/out4[%d] is null", i);
+    if ((!canopy[i] && !(lidf_in && (i == 1 || i == 2))) || !out4[i])      // LIDFa, LIDFb are unused with a given lidf
+      return fail(ctx, SPART_ERR_INVALID, "spart_sailh_batch: canopy/out4[%d] is null", i);
   for (int i = 0; i < 3; ++i)
     if (!angles[i]) return fail(ctx, SPART_ERR_INVALID, "spart_sailh_batch: angles[%d] is null", i);
   return guarded(ctx, "spart_sailh_batch", wsp, ws.total, st, [&] {
-    return dtype == SPART_F32 ? sailh_impl<float>(ctx, B, rho, tau, rs, canopy, angles, out4, wsp, ws, st)
-                              : sailh_impl<double>(ctx, B, rho, tau, rs, canopy, angles, out4, wsp, ws, st);
+    return dtype == SPART_F32 ? sailh_impl<float>(ctx, B, rho, tau, rs, canopy, angles, lidf_in, nlayers, out4, wsp, ws, st)
+                              : sailh_impl<double>(ctx, B, rho, tau, rs, canopy, angles, lidf_in, nlayers, out4, wsp, ws, st);
   });
 }
 
@@ -965,8 +979,11 @@ int spart_run_batch(spart_ctx* ctx, int dtype, int64_t B, const double* const pa
   if (ctx->nb == 0) return fail(ctx, SPART_ERR_NOSENSOR, "spart_run_batch: context has no sensor");
   if (!params || !R_TOC || !R_TOA || !L_TOA) return fail(ctx, SPART_ERR_INVALID, "spart_run_batch: null argument");
   for (int i = 0; i < SPART_NPARAM; ++i)
-    if (!params[i] && !(opt && opt->rdry_in && i >= 9 && i <= 11))   // B, lat, lon are unused with user dry spectra
+    if (!params[i] && !(opt && opt->rdry_in && i >= 9 && i <= 11)    // B, lat, lon are unused with user dry spectra
+        && !(opt && opt->lidf_in && (i == 16 || i == 17)))           // LIDFa, LIDFb are unused with a given lidf
       return fail(ctx, SPART_ERR_INVALID, "spart_run_batch: params[%d] is null", i);
+  if (opt && (opt->nlayers < 0 || opt->nlayers > SPART_MAX_NLAYERS))
+    return fail(ctx, SPART_ERR_INVALID, "spart_run_batch: nlayers = %d (0 = the default 60, else 1 ... %d)", opt->nlayers, SPART_MAX_NLAYERS);
   if (dtype == SPART_F64 && opt && opt->f32_bands &&
       (opt->leaf_refl || opt->leaf_tran || opt->leaf_kchl || opt->soil_refl || opt->soil_refl_dry || opt->rso || opt->rdo ||
        opt->rsd || opt->rdd || opt->band_mean || opt->rdry_in || opt->f32_columns))

@@ -34,11 +34,13 @@ struct ParamPtrs {
   const double* p[NPARAM];
   const double* rho_th;
   const double* tau_th;
+  const double* lidf;   // optional (B, 13) row-major canopy.lidf as the caller set it (sailh.py:51); read by k_prelude<., true> only
+  int nlayers;          // canopy.nlayers (sailh.py:48); read by k_prelude<., true> only
 };
 
 // ------------------------------------------------------------------------------------------
 // Workspace layout of the per-sample quantities: STRUCTURE OF ARRAYS with row pitch Bp (= B rounded up to 64):
-//   cst[i][s]  (NCONST = 40 rows, 36 used, float and / or double), atm[i][s] (16 rows, 15 used, double).
+//   cst[i][s]  (NCONST = 40 rows, 36 used, float and / or double), atm[i][s] (16 rows, 13 used, double).
 // Every kernel that has the sample on its lanes (prelude, column kernel) then reads and writes
 // them coalesced; the band kernels (band on lanes) stage 32 samples x 40 constants per workgroup copy.
 inline int64_t row_pitch_of(int64_t B) { return (B + 63) & ~int64_t(63); }
@@ -130,12 +132,14 @@ struct PreludeStore {            // sample_prelude_to's sink: straight to the st
 #ifndef SPART_PRELUDE_SORT
 #define SPART_PRELUDE_SORT 1
 #endif
-template <bool FAST>
+// USER: the call carries canopy state of its own -- pp.lidf (the 12 fixed-point solves are then skipped: no sort either)
+// and / or pp.nlayers; the default instantiation does not look at either.
+template <bool FAST, bool USER = false>
 __global__ __launch_bounds__(256, SPART_PRELUDE_WAVES) void k_prelude(ParamPtrs pp, int mask, int64_t B, int64_t Bp, float* __restrict__ cstF,
                                                  double* __restrict__ cstD, double* __restrict__ atm) {
   const int64_t base = (int64_t)blockIdx.x * blockDim.x;
   int64_t s = base + threadIdx.x;
-  if (SPART_PRELUDE_SORT && !FAST && (mask & PRE_CANOPY)) {      // (block-uniform condition)
+  if (SPART_PRELUDE_SORT && !FAST && (mask & PRE_CANOPY) && !(USER && pp.lidf)) {      // (block-uniform condition)
     constexpr int NB = 32;
     __shared__ int cnt[NB], start[NB];
     __shared__ unsigned char perm[256];
@@ -163,7 +167,11 @@ __global__ __launch_bounds__(256, SPART_PRELUDE_WAVES) void k_prelude(ParamPtrs 
   double rho_th = pp.rho_th ? pp.rho_th[s] : 0.01;  // LeafBiology defaults (prospect_5d.py:82-83)
   double tau_th = pp.tau_th ? pp.tau_th[s] : 0.01;
   PreludeStore out{cstF, cstD, atm, Bp, s};
-  sample_prelude_to<FAST>([&pp, s](int i) { return pp.p[i] ? pp.p[i][s] : 0.0; }, rho_th, tau_th, mask, out);
+  if (USER)
+    sample_prelude_to<FAST, true>([&pp, s](int i) { return pp.p[i] ? pp.p[i][s] : 0.0; }, rho_th, tau_th, mask, out,
+                                  pp.lidf ? pp.lidf + s * NLINCL : nullptr, pp.nlayers);
+  else
+    sample_prelude_to<FAST>([&pp, s](int i) { return pp.p[i] ? pp.p[i][s] : 0.0; }, rho_th, tau_th, mask, out);
 }
 
 // leaf-angle distribution only (CanopyStructure.lidf, sailh.py:348)
@@ -549,7 +557,12 @@ __global__ __launch_bounds__(64 * COL_WAVES, SPART_COLUMNS_WAVES) void k_columns
 #pragma unroll
     for (int q = 0; q < 5; ++q) v[q] = y0[q] + (y1[q] - y0[q]) * f;    // np.interp (SPART.py:220-223)
     double* kw = lds_k + wave * 64;
-    kw[lane] = kv;                                       // (LDS serves a wave's instructions in order: the reads below see it)
+    kw[lane] = kv;
+    // the reads below are other lanes' words: a wavefront-scope release fence + wave barrier make the store visible to the
+    // wave under the HIP memory model (neither emits an instruction: LDS serves one wave's accesses in order)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const SmacOut so = smac_band_c(a, [kw](int r) { return kw[r]; });
     const double La = a[A_LAF] * econv[j];               // SPART.py:353, 394
     double rtoc, rtoa, ltoa;

@@ -1173,26 +1173,29 @@ SPART_HD double hotspot_J(double A, double C, double alpha, double a, double iA,
   return Md::one_minus_exp_neg(zL, EL) * iA + C * ialpha * (hotspot_g1(a, C) - EL * tL * hotspot_g1(a, C * tL));
 }
 
-SPART_HD bool hotspot_series(double A, double C, double alpha, double& int_canopy, double& pso2w) {
+// nl = canopy.nlayers (sailh.py:48): it enters the model ONLY through the width dx = 1 / nl of the stretch below the canopy
+// (Pso[nl], :131-135, 219) -- sum(Pso[0:nl]) iLAI = LAI int_{-1}^{0} f whatever nl is (:216).  The default (the constant
+// NLAYER, folded at compile time) is the SAIL assumption of CanopyStructure (:345).
+SPART_HD bool hotspot_series(double A, double C, double alpha, double& int_canopy, double& pso2w, int nl = NLAYER) {
   using Md = Mx<double>;
   // C <= 8: Kummer's series needs <= ~45 terms; A + alpha >= 2: otherwise the integrand is nearly flat, two panels do, and
   // the bracket of J would lose digits (its relative gap is ~ alpha L)
   if (!(C > 0.0 && C <= 8.0 && A + alpha >= 2.0 && A > 1e-3 && alpha > 0.0 && alpha < 1e300)) return false;
-  const double dx = 1.0 / NLAYER;
+  const double dx = 1.0 / nl;
   const double ialpha = Md::rcp(alpha), iA = Md::rcp(A), a = A * ialpha;
   const double t1 = Md::exp_poly(-alpha), td = Md::exp_poly(-alpha * dx);
   // int_{-1}^{0} f = J(A, C, alpha, 1);  f(-1 - u) = f(-1) exp(-A u + C t1 (1 - e^(-alpha u))):
   // int_{-1-dx}^{-1} f = f(-1) J(A, C t1, alpha, dx),  f(-1) = exp(-(A - C (1 - t1)))
   int_canopy = hotspot_J(A, C, alpha, a, iA, ialpha, 1.0, t1);
   const double f1 = Md::exp_poly(-(A - C * Md::one_minus_exp_neg(alpha, t1)));
-  pso2w = f1 * hotspot_J(A, C * t1, alpha, a, iA, ialpha, dx, td) * (double)NLAYER;
+  pso2w = f1 * hotspot_J(A, C * t1, alpha, a, iA, ialpha, dx, td) * (double)nl;
   return true;
 }
 
 template <bool FAST>
 SPART_HD void hotspot_integrals(double K, double k, double LAI, double q, double dso, double& int_canopy,
-                                double& pso2w) {
-  const double dx = 1.0 / NLAYER;
+                                double& pso2w, int nl = NLAYER) {
+  const double dx = 1.0 / nl;
   PsoFn f;
   double rate;
   if (dso != 0.0) {
@@ -1204,7 +1207,7 @@ SPART_HD void hotspot_integrals(double K, double k, double LAI, double q, double
 #ifndef SPART_HOTSPOT_SERIES
 #define SPART_HOTSPOT_SERIES 1
 #endif
-    if (SPART_HOTSPOT_SERIES && hotspot_series(f.A, f.C, f.alpha, int_canopy, pso2w)) return;
+    if (SPART_HOTSPOT_SERIES && hotspot_series(f.A, f.C, f.alpha, int_canopy, pso2w, nl)) return;
   } else {
     f.hot = true;
     f.alpha = 0.0;
@@ -1227,7 +1230,19 @@ SPART_HD void hotspot_integrals(double K, double k, double LAI, double q, double
   }
   tot += gl_panel<FAST>(f, lo, 0.0);
   int_canopy = tot;
-  pso2w = gl_panel<FAST>(f, -1.0 - dx, -1.0) / dx;   // smooth there: rate * dx/2 <= 2 unless rate > 240
+  if (nl >= NLAYER) {
+    pso2w = gl_panel<FAST>(f, -1.0 - dx, -1.0) / dx;   // smooth there: rate * dx/2 <= 2 unless rate > 240
+  } else {
+    // fewer, thicker layers (a user's canopy.nlayers): the stretch [-1 - dx, -1] in panels no wider than the default's 1/60
+    const int npan = (NLAYER + nl - 1) / nl;
+    const double h = dx / npan;
+    double acc = 0.0, hi = -1.0;
+    for (int i = 0; i < npan; ++i) {
+      acc += gl_panel<FAST>(f, hi - h, hi);
+      hi -= h;
+    }
+    pso2w = acc / dx;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1240,11 +1255,16 @@ enum PreludeMask { PRE_LEAF = 1, PRE_SOIL = 2, PRE_CANOPY = 4, PRE_ATM = 8, PRE_
 // that a kernel can store them straight to memory instead of holding 64 float64 values in registers across the
 // LIDF iteration and the hot-spot quadrature (k_prelude: 262 -> fewer VGPRs, two waves per SIMD instead of one).
 // Groups excluded by `mask` are not written at all.
-template <bool FAST, typename In, typename Out>
+// USER (the canopy state the reference's SAILH reads from the object at call time, sailh.py:48, 51): lidf_row = the sample's
+// canopy.lidf[13] (nullptr: derived from LIDFa / LIDFb as below) and nl_user = canopy.nlayers.  Without USER both are
+// compile-time facts (no lidf pointer, NLAYER) and the code is the one every earlier round measured.
+template <bool FAST, bool USER = false, typename In, typename Out>
 SPART_HD void sample_prelude_to(const In& in /* in(i) = parameter i of 27, read when first needed */, double rho_th,
-                                double tau_th, int mask, Out& out) {
+                                double tau_th, int mask, Out& out, const double* lidf_row = nullptr, int nl_user = NLAYER) {
   SPART_NO_CONTRACT
   const double d2r = PI / 180.0;
+  const int nl = USER ? nl_user : NLAYER;
+  const bool given = USER && lidf_row != nullptr;
   if (mask & PRE_LEAF) {
   // ---- leaf (prospect_5d.py:135-155, 170-179)
   double Cab = in(0), Cdm = in(1), Cw = in(2), Cs = in(3), Cca = in(4), Cant = in(5), N = in(6), PROT = in(7), CBC = in(8);
@@ -1289,7 +1309,7 @@ SPART_HD void sample_prelude_to(const In& in /* in(i) = parameter i of 27, read 
   double tts = in(19), tto = in(20), rel = in(21);
   if (mask & PRE_CANOPY) {
   // ---- canopy geometry (sailh.py:46-105)
-  double LAI = in(15), LIDFa = in(16), LIDFb = in(17), q = in(18);
+  double LAI = in(15), LIDFa = given ? 0.0 : in(16), LIDFb = given ? 0.0 : in(17), q = in(18);
   double psi = ::fabs(rel - 360.0 * ::rint(rel / 360.0));  // :65 (Python round = half-to-even = rint)
   double psi_rad = psi * d2r;
   double sin_tts = ::sin(tts * d2r), cos_tts = ::cos(tts * d2r), tan_tts = ::tan(tts * d2r);
@@ -1299,11 +1319,16 @@ SPART_HD void sample_prelude_to(const In& in /* in(i) = parameter i of 27, read 
   double dso = ::sqrt(tan_tts * tan_tts + tan_tto * tan_tto - 2.0 * tan_tts * tan_tto * cos_psi);  // :78
   double ks = 0, ko = 0, bf = 0, sob = 0, sof = 0, Fprev = 0;
   for (int i = 0; i < NLINCL; ++i) {
-    double F = (i < NLINCL - 1) ? (FAST ? lidf_dcum_newton(LIDFa, LIDFb, i)
-                                        : lidf_dcum_lit(LIDFa, LIDFb, i))
-                                : 1.0;
-    double li = F - Fprev;
-    Fprev = F;
+    double li;
+    if (given) {
+      li = lidf_row[i];                                           // canopy.lidf as handed in (sailh.py:51)
+    } else {
+      double F = (i < NLINCL - 1) ? (FAST ? lidf_dcum_newton(LIDFa, LIDFb, i)
+                                          : lidf_dcum_lit(LIDFa, LIDFb, i))
+                                  : 1.0;
+      li = F - Fprev;
+      Fprev = F;
+    }
     out.l(i, li);
     double sl = lidf_sin_litab(i), cl = lidf_cos_litab(i);   // sin / cos of litab(i), sailh.py:81
     double chi_s, chi_o, frho, ftau;
@@ -1326,7 +1351,7 @@ SPART_HD void sample_prelude_to(const In& in /* in(i) = parameter i of 27, read 
   out.c(C_TOO, too);
   out.c(C_Z, (1.0 - tss * too) / (ko + ks));             // :203
   double ic, p2w;
-  hotspot_integrals<FAST>(ko, ks, LAI, q, dso, ic, p2w);
+  hotspot_integrals<FAST>(ko, ks, LAI, q, dso, ic, p2w, nl);
   out.c(C_HOT, ic * LAI);   // sum(Pso[0:60]) * iLAI  (:216)
   out.c(C_PSO2W, p2w);      // Pso[60]               (:219)
   }
@@ -1371,12 +1396,13 @@ template <typename T> struct PreludeArrays {
 };
 template <typename T, bool FAST = false>
 SPART_HD void sample_prelude(const double* p /*[27]*/, double rho_th, double tau_th, int mask, T* cst /*[NCONST]*/,
-                             double* atm /*[NATM]*/, double* lidf_out /*[13]*/) {
+                             double* atm /*[NATM]*/, double* lidf_out /*[13]*/, const double* lidf_in = nullptr, int nl = 0) {
   for (int i = 0; i < NCONST; ++i) cst[i] = T(0);
   for (int i = 0; i < NATM; ++i) atm[i] = 0.0;
   for (int i = 0; i < NLINCL; ++i) lidf_out[i] = 0.0;
   PreludeArrays<T> out{cst, atm, lidf_out};
-  sample_prelude_to<FAST>([p](int i) { return p[i]; }, rho_th, tau_th, mask, out);
+  if (lidf_in || nl > 0) sample_prelude_to<FAST, true>([p](int i) { return p[i]; }, rho_th, tau_th, mask, out, lidf_in, nl > 0 ? nl : NLAYER);
+  else sample_prelude_to<FAST>([p](int i) { return p[i]; }, rho_th, tau_th, mask, out);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -8,6 +8,8 @@ LIB_PATH = os.path.normpath(os.path.join(HERE, "..", "libspart_hip.so"))
 
 SPART_F32, SPART_F64 = 0, 1
 NPARAM, NCOEF, NWL, NWLS, NLINCL = 27, 48, 2001, 2162, 13
+NLAYERS = 60            # SPART_NLAYERS: CanopyStructure's default (sailh.py:345)
+ABI_VERSION = 6         # SPART_ABI_VERSION of include/spart_hip.h this binding was written against
 
 c_dp = ctypes.POINTER(ctypes.c_double)
 vp = ctypes.c_void_p
@@ -24,7 +26,9 @@ class SpartMaterialize(ctypes.Structure):
                                   "rsd", "rdd", "rsoil", "La", "rdry_in", "band_mean")] + [("prune_unused_bands", ctypes.c_int32),
                                                                                           ("f32_columns", ctypes.c_int32),
                                                                                           ("f32_bands", ctypes.c_int32),
-                                                                                          ("fast_prelude", ctypes.c_int32)]
+                                                                                          ("fast_prelude", ctypes.c_int32),
+                                                                                          ("lidf_in", vp),
+                                                                                          ("nlayers", ctypes.c_int32)]
 
 
 # name -> (restype, argtypes): every symbol include/spart_hip.h declares
@@ -33,6 +37,7 @@ SIGNATURES = {
     "spart_ctx_destroy": (ctypes.c_int, [vp]),
     "spart_last_error": (ctypes.c_char_p, [vp]),
     "spart_build_id": (ctypes.c_char_p, []),
+    "spart_abi_version": (ctypes.c_int, []),
     "spart_ctx_nb": (ctypes.c_int, [vp]),
     "spart_ctx_econv": (ctypes.c_int, [vp, c_dp]),
     "spart_ctx_set_row_pitch": (ctypes.c_int, [vp, ctypes.c_int64, ctypes.c_int64]),
@@ -44,7 +49,7 @@ SIGNATURES = {
                                        ctypes.c_size_t, vp]),
     "spart_lidf_batch": (ctypes.c_int, [vp, ctypes.c_int64, vp, vp, vp, vp]),
     "spart_sailh_batch": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int64, vp, vp, vp, ctypes.POINTER(vp),
-                                         ctypes.POINTER(vp), ctypes.POINTER(vp), vp, ctypes.c_size_t, vp]),
+                                         ctypes.POINTER(vp), vp, ctypes.c_int32, ctypes.POINTER(vp), vp, ctypes.c_size_t, vp]),
     "spart_smac_batch": (ctypes.c_int, [vp, ctypes.c_int64, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp),
                                         vp, ctypes.c_size_t, vp]),
     "spart_run_batch": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int64, ctypes.POINTER(vp), vp, vp, vp, vp, vp,
@@ -128,6 +133,17 @@ def load(path=None):
             f"{path} is missing: build it with `python spart-python_amd/build.py` "
             "(hipcc, gfx950). spart_amd has no CPU fallback.")
     lib = ctypes.CDLL(path)
+    # the interface version first: a library built from another round's header (SPART_HIP_LIB=, lib_path=) would otherwise be
+    # called with shifted arguments / a shorter spart_materialize
+    try:
+        lib.spart_abi_version.restype = ctypes.c_int
+        have_abi = int(lib.spart_abi_version())
+    except AttributeError:
+        have_abi = None
+    if have_abi != ABI_VERSION:
+        raise RuntimeError(f"{path} implements interface version {have_abi if have_abi is not None else '< 6 (no spart_abi_version)'}"
+                           f", this binding needs {ABI_VERSION} (include/spart_hip.h: SPART_ABI_VERSION); rebuild it with "
+                           "`python spart-python_amd/build.py`")
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export it
         fn.restype = res

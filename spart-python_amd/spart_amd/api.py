@@ -256,8 +256,12 @@ def calculate_leafangles(LIDFa, LIDFb, device=None):
 
 
 class CanopyStructure:
-    """sailh.py:304-348.  ``lidf`` is evaluated on first access (the reference computes it in
-    the constructor); the full-chain kernel derives it itself from LIDFa / LIDFb."""
+    """sailh.py:304-348.  The reference's constructor evaluates ``lidf = calculate_leafangles(LIDFa, LIDFb)`` once and SAILH
+    reads ``canopy.lidf`` and ``canopy.nlayers`` from the object at call time (sailh.py:48, 51) -- never LIDFa / LIDFb
+    again.  The same holds here: the distribution is bound to the constructor's (LIDFa, LIDFb) (editing ``LIDFa`` afterwards
+    changes nothing, as upstream), ``lidf`` may be assigned ((13,), (13, 1) or (B, 13)) or edited in place, and ``nlayers`` is
+    honoured (one integer per call).  ``lidf`` itself is evaluated on first access; until then the kernels derive it from
+    the bound (LIDFa, LIDFb) with the same routine (bit-identical)."""
 
     def __init__(self, LAI, LIDFa, LIDFb, q):
         self.LAI = LAI
@@ -267,16 +271,41 @@ class CanopyStructure:
         self.nlayers = 60
         self.nlincl = 13
         self.nlazi = 36
+        snap = lambda v: np.array(v, dtype=np.float64, copy=True) if isinstance(v, (np.ndarray, list, tuple)) else v  # noqa: E731
+        self._lidf_ab = (snap(LIDFa), snap(LIDFb))      # what sailh.py:348 evaluated lidf from
         self._lidf = None
 
     @property
     def lidf(self):
         if self._lidf is None:
-            self._lidf = calculate_leafangles(self.LIDFa, self.LIDFb)
+            self._lidf = calculate_leafangles(*self._lidf_ab)
         return self._lidf
 
+    @lidf.setter
+    def lidf(self, value):
+        self._lidf = value
+
     def columns(self):
-        return [self.LAI, self.LIDFa, self.LIDFb, self.q]
+        """[LAI, LIDFa, LIDFb, q] as SAILH sees them: the (LIDFa, LIDFb) the distribution is bound to (None, None once ``lidf``
+        exists as an array: the kernels then take :meth:`lidf_state` instead)."""
+        if self._lidf is not None:
+            return [self.LAI, None, None, self.q]
+        return [self.LAI, self._lidf_ab[0], self._lidf_ab[1], self.q]
+
+    def lidf_state(self):
+        """``lidf`` once it exists as an array (assigned, or read -- the caller may have edited it in place), else None."""
+        return self._lidf
+
+
+def _canopy_state(canopy):
+    """(columns, lidf | None, nlayers | None) of a canopy object: ours, or any object with the reference's attributes."""
+    if isinstance(canopy, CanopyStructure):
+        cols, lidf = canopy.columns(), canopy.lidf_state()
+    else:
+        lidf = getattr(canopy, "lidf", None)
+        cols = [canopy.LAI, None if lidf is not None else canopy.LIDFa, None if lidf is not None else canopy.LIDFb, canopy.q]
+    nl = getattr(canopy, "nlayers", 60)
+    return cols, lidf, (None if (isinstance(nl, (int, np.integer)) and not isinstance(nl, bool) and int(nl) == 60) else nl)
 
 
 def SAILH(soil, leafopt, canopy, angles, dtype="float64", device=None):
@@ -292,8 +321,9 @@ def SAILH(soil, leafopt, canopy, angles, dtype="float64", device=None):
             "\n the neccessary thermal wavelengths."
         )
     eng = _engine.get_engine(None, device)
-    out = eng.sailh(leafopt.refl, leafopt.tran, soil.refl, canopy.columns(), angles.columns(), dtype)
-    sc = out[0].shape[0] == 1 and _is_scalar(*canopy.columns(), *angles.columns())
+    ccols, lidf, nl = _canopy_state(canopy)            # canopy.lidf / canopy.nlayers, read here as sailh.py:48, 51 read them
+    out = eng.sailh(leafopt.refl, leafopt.tran, soil.refl, ccols, angles.columns(), dtype, canopy_lidf=lidf, nlayers=nl)
+    sc = out[0].shape[0] == 1 and _is_scalar(*[c for c in ccols if c is not None], *angles.columns())
     return CanopyReflectances(*[_colvec(o, sc) for o in out])
 
 
@@ -475,7 +505,7 @@ class SPART:
         self._sensor = sensor
 
     def _columns(self):
-        return (self.leafbio.columns() + self.soilpar.columns() + self.canopy.columns() + self.angles.columns()
+        return (self.leafbio.columns() + self.soilpar.columns() + _canopy_state(self.canopy)[0] + self.angles.columns()
                 + self.atm.columns() + [self.DOY])
 
     _LAZY = ("atmopt", "leafopt", "soilopt", "canopyopt")
@@ -504,6 +534,7 @@ class SPART:
             fields += _SPECTRA
         rdry = self.soilpar.rdry if getattr(self.soilpar, "rdry_set", False) else None
         th = (self.leafbio.rho_thermal, self.leafbio.tau_thermal)
+        _, clidf, nlay = _canopy_state(self.canopy)      # canopy.lidf / canopy.nlayers as SAILH reads them (sailh.py:48, 51)
         # the (B, nb) results share ONE device block, so that they come back in one device-to-host copy
         import torch
         ncol = ["R_TOC", "R_TOA", "L_TOA", "La"] + (["rsoil"] if debug else [])
@@ -511,10 +542,12 @@ class SPART:
         if rdry is not None:
             r0 = rdry if torch.is_tensor(rdry) else np.asarray(rdry)
             B = max(B, 1 if (r0.ndim == 1 or (r0.ndim == 2 and r0.shape[1] == 1)) else r0.shape[0])
+        if clidf is not None and np.ndim(clidf) == 2 and np.shape(clidf)[1] != 1:
+            B = max(B, int(np.shape(clidf)[0]))
         td = torch.float32 if _engine.DTYPES[self.dtype] == 0 else torch.float64
         blk = torch.empty((len(ncol), B, eng.nb), dtype=td, device=eng.device)
         res = eng.run(cols, self.dtype, rho_thermal=th[0], tau_thermal=th[1], materialize=fields, rdry=rdry,
-                      prune=not materialize, out={k: blk[i] for i, k in enumerate(ncol)})
+                      prune=not materialize, out={k: blk[i] for i, k in enumerate(ncol)}, canopy_lidf=clidf, nlayers=nlay)
         host = _np(blk)
         out = {k: (host[ncol.index(k)] if k in ncol else _np(v)) for k, v in res.items()}
         scalar = _is_scalar(*[c for c in cols if c is not None]) and out["R_TOC"].shape[0] == 1
@@ -526,7 +559,7 @@ class SPART:
         # attributes eagerly in run(): mutating an input array in place or changing sp.dtype afterwards must not change them)
         snap = lambda c: None if c is None else (np.array(c, copy=True) if isinstance(c, np.ndarray) else (c.clone() if hasattr(c, "clone") else c))  # noqa: E731
         self.__dict__["_last"] = dict(eng=eng, dtype=self.dtype, cols=[snap(c) for c in cols], th=tuple(snap(t) for t in th),
-                                      rdry=snap(rdry), scalar=scalar,
+                                      rdry=snap(rdry), scalar=scalar, clidf=snap(clidf), nlayers=nlay,
                                       angles=[snap(c) for c in self.angles.columns()], atm=[snap(c) for c in self.atm.columns()])
         for k in self._LAZY:
             self.__dict__.pop(k, None)
@@ -559,7 +592,7 @@ class SPART:
                 self.__dict__["atmopt"] = AtmosphericOptics(*[_np(sm[f]) for f in _engine.SMAC_FIELDS])
             else:
                 res = eng.run(last["cols"], last["dtype"], rho_thermal=last["th"][0], tau_thermal=last["th"][1],
-                              materialize=_SPECTRA, rdry=last["rdry"])
+                              materialize=_SPECTRA, rdry=last["rdry"], canopy_lidf=last["clidf"], nlayers=last["nlayers"])
                 self._set_spectra({k: _np(res[k]) for k in _SPECTRA}, last["scalar"])
             return self.__dict__[name]
         raise AttributeError(f"{type(self).__name__!r} object has no attribute {name!r}")

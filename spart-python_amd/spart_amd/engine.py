@@ -228,6 +228,38 @@ class Engine:
                 out[i] = self.to_f64(c, B)
         return out, B
 
+    def _lidf_rows(self, lidf, B):
+        """canopy.lidf as the caller set it -> (B, 13) contiguous float64 device tensor, B possibly raised to its row count.
+        Accepted: (13,), the reference's (13, 1) column (sailh.py:396), or (B, 13) rows."""
+        torch = self.torch
+        x = lidf if torch.is_tensor(lidf) else torch.as_tensor(np.asarray(lidf, dtype=np.float64))
+        x = x.to(device=self.device, dtype=torch.float64)
+        if x.dim() == 1 or (x.dim() == 2 and x.shape[1] == 1 and x.shape[0] == _lib.NLINCL):
+            x = x.reshape(1, -1)
+        if x.dim() != 2 or x.shape[1] != _lib.NLINCL:
+            raise ValueError(f"canopy.lidf of shape {tuple(np.shape(lidf))}: expected ({_lib.NLINCL},), ({_lib.NLINCL}, 1) or (B, {_lib.NLINCL})")
+        if x.shape[0] != B:
+            if x.shape[0] == 1:
+                x = x.expand(B, _lib.NLINCL)
+            elif B != 1:
+                raise ValueError(f"canopy.lidf has {x.shape[0]} rows for a batch of {B}")
+        return x.contiguous()
+
+    @staticmethod
+    def _nlayers(n):
+        """canopy.nlayers -> the C ABI's int (0 = default).  The reference slices Pso[0:nl] (sailh.py:216): integers only."""
+        if n is None:
+            return 0
+        import numbers
+        if isinstance(n, bool) or not isinstance(n, (numbers.Integral, np.integer)):
+            if np.ndim(n) != 0:
+                raise ValueError("canopy.nlayers must be ONE integer per call (sailh.py:48)")
+            raise TypeError(f"canopy.nlayers must be an integer, got {type(n).__name__} (the reference slices Pso[0:nl], sailh.py:216)")
+        n = int(n)
+        if n < 1 or n > 1000000:
+            raise ValueError(f"canopy.nlayers = {n}: expected 1 ... 1000000")
+        return n
+
     def _ptrs(self, tensors):
         arr = (_lib.vp * len(tensors))(*[t.data_ptr() if t is not None else None for t in tensors])
         return arr
@@ -307,13 +339,25 @@ class Engine:
         _lib.check(self.lib, self.ctx, rc)
         return out
 
-    def sailh(self, rho, tau, rs, canopy4, angles3, dtype="float64"):
-        """SAILH (sailh.py:14-237) on (B,2162) spectra."""
+    def sailh(self, rho, tau, rs, canopy4, angles3, dtype="float64", canopy_lidf=None, nlayers=None):
+        """SAILH (sailh.py:14-237) on (B,2162) spectra.  canopy_lidf / nlayers: canopy.lidf ((13,), (13,1) or (B,13)) and
+        canopy.nlayers as the reference reads them from the object at call time (sailh.py:48, 51); None = derived from
+        LIDFa / LIDFb, 60."""
         dt = DTYPES[dtype]
-        cols, B = self.columns(list(canopy4) + list(angles3))
+        nl = self._nlayers(nlayers)
+        canopy4 = list(canopy4)
+        if canopy_lidf is not None:
+            canopy4[1] = 0.0 if canopy4[1] is None else canopy4[1]
+            canopy4[2] = 0.0 if canopy4[2] is None else canopy4[2]
+        cols, B = self.columns(canopy4 + list(angles3))
         for x in (rho, tau, rs):
             n = x.shape[0] if (hasattr(x, "ndim") and x.ndim == 2 and x.shape[1] != 1) else 1
             B = max(B, n)
+        li = None
+        if canopy_lidf is not None:
+            nrow = 1 if (np.ndim(canopy_lidf) == 1 or np.shape(canopy_lidf)[-1] == 1) else np.shape(canopy_lidf)[0]
+            B = max(B, nrow)
+            li = self._lidf_rows(canopy_lidf, B)
         cols = [c.expand(B).contiguous() if c.numel() == 1 else c for c in cols]
         rho, tau, rs = (self._spec(x, B, _lib.NWLS, dt) for x in (rho, tau, rs))
         td = self._tdtype(dt)
@@ -321,8 +365,8 @@ class Engine:
         ws, wsn = self._workspace(dt, B)
         self.calls["spart_sailh_batch"] += 1
         rc = self.lib.spart_sailh_batch(self.ctx, dt, B, rho.data_ptr(), tau.data_ptr(), rs.data_ptr(),
-                                        self._ptrs(cols[:4]), self._ptrs(cols[4:]), self._ptrs(out), ws, wsn,
-                                        self._stream())
+                                        self._ptrs(cols[:4]), self._ptrs(cols[4:]), li.data_ptr() if li is not None else None,
+                                        nl, self._ptrs(out), ws, wsn, self._stream())
         _lib.check(self.lib, self.ctx, rc)
         return out
 
@@ -338,7 +382,8 @@ class Engine:
         return dict(zip(SMAC_FIELDS, out))
 
     def run(self, params, dtype="float32", rho_thermal=None, tau_thermal=None, materialize=(), out=None,
-            prune=False, rdry=None, f32_columns=False, f32_bands=False, lidf="literal", _workspace=None):
+            prune=False, rdry=None, f32_columns=False, f32_bands=False, lidf="literal", _workspace=None,
+            canopy_lidf=None, nlayers=None):
         """SPART(...).run() for every column of ``params`` (SPART.py:162-269).
 
         params : (27, B) float64 device tensor (rows = spart_amd.workloads.PARAM_NAMES) or a list of 27
@@ -358,6 +403,10 @@ class Engine:
         f32_columns : float32 only.  False (default): the bands the sensor columns depend on are re-evaluated in
                float64, the columns are the float64 mode's values rounded to float32; True: columns straight from
                the float32 band arithmetic (spart_materialize.f32_columns)
+        canopy_lidf : optional canopy.lidf as the caller set it, (13,), (13,1) or (B,13) (spart_materialize.lidf_in; the
+               reference's SAILH reads it from the object, sailh.py:51); the LIDFa / LIDFb entries of ``params`` are then
+               ignored (may be None in a list)
+        nlayers : optional canopy.nlayers, one integer per call (spart_materialize.nlayers; sailh.py:48); None = 60
         """
         torch = self.torch
         dt = DTYPES[dtype]
@@ -369,7 +418,13 @@ class Engine:
             B = P.shape[1]
             cols = [P[i] for i in range(_lib.NPARAM)]
         else:
-            plist = [0.0 if (p is None and rdry is not None) else p for p in params]
+            plist = [0.0 if (p is None and (rdry is not None or (canopy_lidf is not None and i in (16, 17)))) else p
+                     for i, p in enumerate(params)]
+            if len(plist) != _lib.NPARAM:
+                raise ValueError(f"params must have {_lib.NPARAM} entries, got {len(plist)}")
+            for i, p in enumerate(plist):
+                if p is None:
+                    raise ValueError(f"params[{i}] is None (only B / lat / lon with rdry= and LIDFa / LIDFb with canopy_lidf= may be)")
             cols, B = self.columns(plist)
             if rdry is not None:
                 r0 = rdry if torch.is_tensor(rdry) else np.asarray(rdry)
@@ -377,6 +432,13 @@ class Engine:
                 if nrow > B:
                     B = nrow
                     cols = [c.expand(B).contiguous() if c.numel() == 1 else c for c in cols]
+            if canopy_lidf is not None:
+                nrow = 1 if (np.ndim(canopy_lidf) == 1 or np.shape(canopy_lidf)[-1] == 1) else np.shape(canopy_lidf)[0]
+                if nrow > B:
+                    B = nrow
+                    cols = [c.expand(B).contiguous() if c.numel() == 1 else c for c in cols]
+        nl = self._nlayers(nlayers)
+        li = self._lidf_rows(canopy_lidf, B) if canopy_lidf is not None else None
         th = [None if x is None else self.to_f64(x, B) for x in (rho_thermal, tau_thermal)]
         res = dict(out) if out is not None else {}       # (the caller's dict is not modified)
         for k in ("R_TOC", "R_TOA", "L_TOA"):
@@ -388,8 +450,10 @@ class Engine:
         rd = None
         if lidf not in ("literal", "newton"):
             raise ValueError("lidf must be 'literal' or 'newton'")
-        if materialize or prune or rdry is not None or f32_columns or f32_bands or lidf == "newton":
+        if materialize or prune or rdry is not None or f32_columns or f32_bands or lidf == "newton" or li is not None or nl:
             mat = _lib.SpartMaterialize()
+            mat.lidf_in = li.data_ptr() if li is not None else None
+            mat.nlayers = nl
             mat.fast_prelude = 1 if lidf == "newton" else 0
             mat.prune_unused_bands = 1 if prune else 0
             mat.f32_columns = 1 if f32_columns else 0

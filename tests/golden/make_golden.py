@@ -29,6 +29,13 @@ Files
                  edited optical_params, and SPART objects whose optipar / ETpar / sensorinfo were edited between
                  construction and run() (SPART.py:93-95 read at :181-184, 192, 202, 216, 228; prospect_5d.py:158-167;
                  bsm.py:45, 54-55): defaults + 8 LHS rows per edit, Sentinel2A (+ MODIS for the sensorinfo edit)
+  canopy_state.npz  the canopy STATE SAILH reads from the object at call time (canopy_edits.py: canopy.lidf assigned / edited in
+                 place / of another (a, b) / un-normalised / 1-D, canopy.nlayers 1, 7, 30, 120, LIDFa edited after construction;
+                 sailh.py:48-54, 93-97, 131-135, 216-219, 348): per edit SAILH(...) on the default optics (16 probe bands + all-band
+                 mean) and SPART(...).run(debug=True) for defaults + 8 LHS rows on Sentinel2A (float64 coefficients) and
+                 TerraAqua-MODIS; and `stale/`: a second run() of ONE object after an edit of optipar / a leafbio field (the
+                 reference's change tracker keeps its first answer, SPART.py:178-209) beside a fresh object's
+                 (python tests/golden/make_golden.py canopy_state)
   edge.npz       128 rows of tools/edge_sweep.py's widened ranges with edge values (LAI 0 / 1e-4 / 10, dry soil, N = 1,
                  zero pigments, exact hot spot, grazing angles, PRO leaves), Sentinel2A: P + R_TOC / R_TOA / L_TOA
 """
@@ -435,6 +442,100 @@ def gen_edge():
         out[k] = np.array([r[j] for r in res])
     np.savez_compressed(os.path.join(HERE, "edge.npz"), **out)
     print("edge", P.shape, "non-finite reference entries:", int((~np.isfinite(out["R_TOC"])).sum()))
+
+
+def _canopy_sailh_row(args):
+    """SAILH(...) with the default optics on a canopy object edited after construction (canopy_edits.CANOPY_EDITS)"""
+    import canopy_edits
+    r, edit, payload = args
+    lo, so = _GRID_STATE.get("optics") or _GRID_STATE.setdefault("optics", default_optics())
+    cs = CanopyStructure(*r[:4])
+    if edit:
+        canopy_edits.CANOPY_EDITS[edit](cs, payload)
+    rad = SAILH(so, lo, cs, Angles(*r[4:7]))
+    sp = [np.asarray(getattr(rad, k), dtype=np.float64).reshape(-1) for k in ("rso", "rdo", "rsd", "rdd")]
+    assert all(x.size == 2162 for x in sp)
+    return np.array([x[GRID_PROBES_CANOPY] for x in sp]), np.array([x.mean() for x in sp]), np.asarray(cs.lidf, dtype=np.float64).reshape(-1)
+
+
+def _canopy_run_row(args):
+    """SPART(...).run(debug=True) on an object whose canopy was edited after construction"""
+    import canopy_edits
+    import table_edits
+    row, sensor, edit, payload = args
+    leaf, soil, can, ang, atm, doy = row[0:9], row[9:15], row[15:19], row[19:22], row[22:26], row[26]
+    with redirect_stdout(io.StringIO()):
+        cs = CanopyStructure(*can)
+        sp = SPART.SPART(SoilParameters(*soil), LeafBiology(*leaf[:7], PROT=leaf[7], CBC=leaf[8]), cs,
+                         AtmosphericProperties(atm[0], atm[1], atm[2], Pa=atm[3]), Angles(*ang), sensor, int(doy))
+        table_edits.upcast_coefs(sp.sensorinfo)
+        if edit:
+            canopy_edits.CANOPY_EDITS[edit](cs, payload)
+        df = sp.run(debug=True)
+    return df["R_TOC"].to_numpy(), df["R_TOA"].to_numpy(), df["L_TOA"].to_numpy(), df["rsoil"].to_numpy()
+
+
+def _stale_rows(sensor):
+    """ONE object, run() twice with an edit in between that no setter sees (SPART.py:178-209: the trackers stay False, the
+    cached leafopt / soilopt are reused): -> (first run, second run, a FRESH object built after the same edit)."""
+    import table_edits
+    d = workloads.default_row()[0]
+
+    def make():
+        sp = SPART.SPART(SoilParameters(*d[9:15]), LeafBiology(*d[0:7]), CanopyStructure(*d[15:19]),
+                         AtmosphericProperties(d[22], d[23], d[24], Pa=d[25]), Angles(*d[19:22]), sensor, 100)
+        table_edits.upcast_coefs(sp.sensorinfo)
+        return sp
+    out = {}
+    cols = ("R_TOC", "R_TOA", "L_TOA")
+    for tag, edit in (("optipar_kab", lambda sp: sp.optipar.__setitem__("Kab", np.asarray(sp.optipar["Kab"], dtype=np.float64) * 1.1)),
+                      ("leafbio_cab", lambda sp: setattr(sp.leafbio, "Cab", 60.0))):
+        with redirect_stdout(io.StringIO()):
+            sp = make()
+            first = sp.run()
+            edit(sp)
+            second = sp.run()
+            fresh = make()
+            edit(fresh)
+            fr = fresh.run()
+        for name, df in (("first", first), ("second", second), ("fresh", fr)):
+            for c in cols:
+                out[f"stale/{sensor}/{tag}/{name}/{c}"] = df[c].to_numpy()
+        print("stale", tag, "second == first:", bool(np.array_equal(second["R_TOC"].to_numpy(), first["R_TOC"].to_numpy())),
+              "fresh moved by %.2e" % np.max(np.abs(fr["R_TOC"].to_numpy() / first["R_TOC"].to_numpy() - 1)), flush=True)
+    return out
+
+
+def gen_canopy_state():
+    import warnings
+    import canopy_edits
+    from SPART.sailh import calculate_leafangles
+    warnings.filterwarnings("ignore")
+    payload = np.asarray(calculate_leafangles(*canopy_edits.OTHER_AB), dtype=np.float64).reshape(-1)
+    out = {"other_ab_lidf": payload, "probe_index": np.array(GRID_PROBES_CANOPY)}
+    d = workloads.default_row()
+    P = np.concatenate([d, workloads.lhs_params(8, "full", seed=31)])
+    # SAILH rows: canopy + angles of the same nine rows, and the exact hot spot (dso == 0) + a small-q / low-sun row
+    rows = np.concatenate([P[:, 15:22], np.array([[3, -0.35, -0.15, 0.05, 30, 30, 0], [2, 0.2, -0.1, 0.01, 60, 30, 160.0]])])
+    out["sailh/rows"] = rows
+    out["run/P"] = P
+    edits = [None] + list(canopy_edits.CANOPY_EDITS)
+    with np.errstate(all="ignore"), Pool(8) as pool:
+        for e in edits:
+            tag = e or "none"
+            res = pool.map(_canopy_sailh_row, [(r, e, payload if e == "other_ab" else None) for r in rows], chunksize=2)
+            out[f"sailh/{tag}/probes"] = np.array([r[0] for r in res])
+            out[f"sailh/{tag}/means"] = np.array([r[1] for r in res])
+            out[f"sailh/{tag}/lidf"] = np.array([r[2] for r in res])
+            for sensor in ("Sentinel2A-MSI", "TerraAqua-MODIS"):
+                rr = pool.map(_canopy_run_row, [(r, sensor, e, payload if e == "other_ab" else None) for r in P], chunksize=2)
+                for j, k in enumerate(["R_TOC", "R_TOA", "L_TOA", "rsoil"]):
+                    out[f"run/{tag}/{sensor}/{k}"] = np.array([r[j] for r in rr])
+            base = out["run/none/Sentinel2A-MSI/R_TOC"]
+            print(tag, "R_TOC moved by up to %.2e against the unedited canopy" %
+                  np.max(np.abs(out[f"run/{tag}/Sentinel2A-MSI/R_TOC"] / base - 1)), flush=True)
+    out.update(_stale_rows("Sentinel2A-MSI"))
+    np.savez_compressed(os.path.join(HERE, "canopy_state.npz"), **out)
 
 
 GRID_PROBES_LEAF = [0, 50, 100, 150, 200, 250, 280, 300, 350, 400, 570, 800, 1050, 1250, 1540, 2000]    # 400 ... 2400 nm

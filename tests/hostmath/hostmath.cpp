@@ -19,13 +19,14 @@ template <typename T> static BandTab<T> tab_at(const double* tab, int i) {
   return t;
 }
 
+// lidf_in (B, 13) / nl: the caller's canopy.lidf / canopy.nlayers (nullptr / 0 = the defaults), as k_prelude<., true> takes them
 template <typename T>
 static void bands_impl(int64_t B, const double* tab, const double* P, double* out /* (B, NEVAL, 10) */,
-                       double* atm_out, double* lidf_out) {
+                       double* atm_out, double* lidf_out, const double* lidf_in = nullptr, int nl = 0) {
   for (int64_t s = 0; s < B; ++s) {
     T c[NCONST];
     double a[NATM], li[NLINCL];
-    sample_prelude<T, (sizeof(T) == 4)>(P + s * NPARAM, 0.01, 0.01, PRE_ALL, c, a, li);
+    sample_prelude<T, (sizeof(T) == 4)>(P + s * NPARAM, 0.01, 0.01, PRE_ALL, c, a, li, lidf_in ? lidf_in + s * NLINCL : nullptr, nl);
     std::memcpy(atm_out + s * NATM, a, sizeof(a));
     std::memcpy(lidf_out + s * NLINCL, li, sizeof(li));
     CanopyPar<T> cp;
@@ -75,6 +76,13 @@ void hm_derive_tables(const double* nr, const double* nw, const double* Kab, con
 void hm_bands(int dtype, int64_t B, const double* tab, const double* P, double* out, double* atm, double* lidf) {
   if (dtype == 0) bands_impl<float>(B, tab, P, out, atm, lidf);
   else bands_impl<double>(B, tab, P, out, atm, lidf);
+}
+
+// the same with the caller's canopy state (sailh.py:48, 51): lidf_in (B, 13) or NULL, nl = canopy.nlayers or 0
+void hm_bands_state(int dtype, int64_t B, const double* tab, const double* P, const double* lidf_in, int nl, double* out,
+                    double* atm, double* lidf) {
+  if (dtype == 0) bands_impl<float>(B, tab, P, out, atm, lidf, lidf_in, nl);
+  else bands_impl<double>(B, tab, P, out, atm, lidf, lidf_in, nl);
 }
 
 // SMAC + TOC->TOA for (B, nb): rv (B, nb, 4) = rso, rdo, rsd, rdd at the band centres

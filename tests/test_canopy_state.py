@@ -1,0 +1,227 @@
+"""canopy.lidf and canopy.nlayers, the two attributes the reference's SAILH reads from the canopy OBJECT at call time
+(sailh.py:48, 51 -> :52-54, 93-97, 131-135, 216-219); VERDICT r5 "Missing 1".
+
+tests/golden/canopy_state.npz holds the REFERENCE's answers for the edits of tests/golden/canopy_edits.py (assigned / in-place
+edited / 1-D / un-normalised distributions, nlayers 1 ... 120, LIDFa edited after construction) through SAILH(...) and
+SPART(...).run().  CPU: the host logic of CanopyStructure; the oracle and the device arithmetic are pinned on this axis in
+tests/test_oracle_golden.py and tests/test_hostmath.py.  GPU: this package's public API with the same edits applied to its own
+CanopyStructure reproduces the fixtures at 1e-9 / 1e-8, in both dtypes, scalar and batched, and through the C ABI directly.
+"""
+import io
+import os
+import sys
+from contextlib import redirect_stdout
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, rel_err
+
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import canopy_edits  # noqa: E402
+import table_edits  # noqa: E402
+
+EDITS = ["none"] + list(canopy_edits.CANOPY_EDITS)
+
+
+@pytest.fixture(scope="module")
+def fx():
+    return np.load(os.path.join(ROOT, "tests", "golden", "canopy_state.npz"))
+
+
+def _apply(cs, edit, fx):
+    if edit != "none":
+        canopy_edits.CANOPY_EDITS[edit](cs, fx["other_ab_lidf"] if edit == "other_ab" else None)
+    return cs
+
+
+# ------------------------------------------------------------------------------------------------ CPU: host logic
+def test_fixture_states_what_the_reference_does(fx):
+    base = fx["run/none/Sentinel2A-MSI/R_TOC"]
+    assert np.array_equal(fx["run/lidfa_after/Sentinel2A-MSI/R_TOC"], base)            # LIDFa after construction: no effect
+    assert np.array_equal(fx["run/flat13/Sentinel2A-MSI/R_TOC"], fx["run/table/Sentinel2A-MSI/R_TOC"])   # (13,) == (13, 1)
+    assert 5e-3 < rel_err(fx["run/nlayers30/Sentinel2A-MSI/R_TOC"], base) < 5e-2        # the verdict's "1 %"
+    assert rel_err(fx["run/uniform/Sentinel2A-MSI/R_TOC"], base) > 1e-2
+    assert rel_err(fx["run/unnormalised/Sentinel2A-MSI/R_TOC"], fx["run/table/Sentinel2A-MSI/R_TOC"]) > 1e-2   # not normalised
+    # the change tracker: a second run() after an edit no setter sees returns the FIRST answer (SPART.py:178-209)
+    for tag in ("optipar_kab", "leafbio_cab"):
+        p = f"stale/Sentinel2A-MSI/{tag}/"
+        assert np.array_equal(fx[p + "second/R_TOC"], fx[p + "first/R_TOC"])
+        assert rel_err(fx[p + "fresh/R_TOC"], fx[p + "first/R_TOC"]) > 1e-2
+
+
+def test_canopy_structure_binds_lidf_like_the_reference():
+    """no GPU: what columns() / lidf_state() hand to the kernels after each kind of edit"""
+    from spart_amd.api import CanopyStructure, _canopy_state
+    cs = CanopyStructure(3, -0.35, -0.15, 0.05)
+    assert cs.nlayers == 60 and cs.nlincl == 13 and cs.nlazi == 36
+    assert _canopy_state(cs) == ([3, -0.35, -0.15, 0.05], None, None)
+    cs.LIDFa, cs.LIDFb = 0.4, 0.1                       # after construction: the distribution keeps the constructor's (a, b)
+    assert _canopy_state(cs)[0] == [3, -0.35, -0.15, 0.05]
+    cs.nlayers = 30
+    assert _canopy_state(cs)[2] == 30
+    cs.nlayers = np.int64(60)
+    assert _canopy_state(cs)[2] is None
+    li = np.full((13, 1), 1 / 13)
+    cs.lidf = li                                        # assignable (was: AttributeError)
+    cols, state, _ = _canopy_state(cs)
+    assert cols == [3, None, None, 0.05] and state is li and cs.lidf is li
+    # array parameters are bound by value
+    a = np.array([0.1, 0.2])
+    cb = CanopyStructure(np.array([1.0, 2.0]), a, np.array([0.0, 0.1]), 0.05)
+    a[0] = 0.9
+    assert np.array_equal(_canopy_state(cb)[0][1], [0.1, 0.2])
+
+    class Ref:                                          # any object with the reference's attributes
+        LAI, LIDFa, LIDFb, q, nlayers = 2.0, 0.1, 0.2, 0.1, 24
+        lidf = li
+    assert _canopy_state(Ref())[0] == [2.0, None, None, 0.1] and _canopy_state(Ref())[2] == 24
+
+
+def test_nlayers_validation_needs_no_gpu():
+    from spart_amd.engine import Engine
+    assert Engine._nlayers(None) == 0 and Engine._nlayers(30) == 30 and Engine._nlayers(np.int32(7)) == 7
+    with pytest.raises(TypeError):
+        Engine._nlayers(30.0)                           # the reference: TypeError from Pso[0:nl] (sailh.py:216)
+    with pytest.raises(TypeError):
+        Engine._nlayers(True)
+    with pytest.raises(ValueError):
+        Engine._nlayers(0)
+    with pytest.raises(ValueError):
+        Engine._nlayers(np.array([30, 60]))
+
+
+# ------------------------------------------------------------------------------------------------ GPU: the public API
+def _default_optics(S):
+    """the reference's default leaf / soil fixtures (tests/conftest.py:48-59) through this package"""
+    op = S.load_optical_parameters()
+    lb = S.LeafBiology(40, 0.01, 0.02, 0, 10, 10, 1.5)
+    lo = S.set_leaf_refl_trans_assumptions(S.PROSPECT_5D(lb, op), lb, S.SpectralBands())
+    so = S.set_soil_refl_trans_assumptions(S.BSM(S.SoilParameters(0.5, 0, 100, 20, 25, 0.015), op), S.SpectralBands())
+    return lo, so
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-9), ("float32", 1e-4)])
+def test_sailh_reads_canopy_state_like_the_reference(fx, dtype, tol):
+    """SPART.SAILH(soil, leafopt, canopy, angles) with canopy.lidf / canopy.nlayers edited exactly as the generator edited the
+    reference's object: 16 probe bands + the all-band mean of rso / rdo / rsd / rdd, scalar calls (the reference's form)."""
+    import SPART as S
+    lo, so = _default_optics(S)
+    probes = fx["probe_index"]
+    rows = fx["sailh/rows"]
+    for e in EDITS:
+        for i, r in enumerate(rows):
+            cs = _apply(S.CanopyStructure(*r[:4]), e, fx)
+            rad = S.SAILH(so, lo, cs, S.Angles(*r[4:7]), dtype=dtype)
+            for j, k in enumerate(("rso", "rdo", "rsd", "rdd")):
+                v = getattr(rad, k)
+                assert v.shape == (2162, 1)
+                assert rel_err(v[probes, 0], fx[f"sailh/{e}/probes"][i, j], 1e-3) < tol, (e, i, k)
+                assert rel_err(v[:, 0].mean(), fx[f"sailh/{e}/means"][i, j], 1e-3) < tol, (e, i, k)
+            if dtype == "float64":
+                assert rel_err(np.asarray(cs.lidf).reshape(-1), fx[f"sailh/{e}/lidf"][i], 1e-12) < 1e-12, (e, i)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sensor", ["Sentinel2A-MSI", "TerraAqua-MODIS"])
+def test_run_reads_canopy_state_like_the_reference(fx, sensor):
+    """SPART.SPART(...).run(debug=True), one scalar object per row, canopy edited between construction and run()."""
+    import SPART as S
+    P = fx["run/P"]
+    for e in EDITS:
+        for dtype, tol in (("float64", 1e-8), ("float32", 1e-4)):
+            got = {k: [] for k in ("R_TOC", "R_TOA", "L_TOA", "rsoil")}
+            for row in (P if dtype == "float64" else P[:3]):
+                leaf, soil, can, ang, atm = row[0:9], row[9:15], row[15:19], row[19:22], row[22:26]
+                with redirect_stdout(io.StringIO()):
+                    cs = S.CanopyStructure(*can)
+                    sp = S.SPART(S.SoilParameters(*soil), S.LeafBiology(*leaf[:7], PROT=leaf[7], CBC=leaf[8]), cs,
+                                 S.AtmosphericProperties(atm[0], atm[1], atm[2], Pa=atm[3]), S.Angles(*ang), sensor, int(row[26]),
+                                 dtype=dtype)
+                    table_edits.upcast_coefs(sp.sensorinfo)
+                    _apply(cs, e, fx)
+                    df = sp.run(debug=True)
+                for k in got:
+                    got[k].append(df[k].to_numpy())
+            n = len(got["R_TOC"])
+            for k in got:
+                assert rel_err(np.array(got[k]), fx[f"run/{e}/{sensor}/{k}"][:n], 1e-6) < tol, (e, sensor, dtype, k)
+
+
+@pytest.mark.gpu
+def test_batched_canopy_state_and_materialised_spectra(fx, oracle, tables):
+    """the same edits as ONE batched call: lidf as (B, 13) rows / one (13,) row broadcast, nlayers per call; the spectra a
+    materialising run returns agree with the oracle given the same state; pruned and full runs give identical columns."""
+    import SPART as S
+    from test_oracle_golden import _edited
+    P = fx["run/P"]
+    B = P.shape[0]
+    for e in ("table", "other_ab", "inplace", "nlayers7", "table_nlayers24", "lidfa_after"):
+        lidf, nl = _edited(oracle, P[:, 15:19], e, fx["other_ab_lidf"])
+        cs = S.CanopyStructure(P[:, 15], P[:, 16], P[:, 17], P[:, 18])
+        if e == "inplace":
+            li = cs.lidf                                # (B, 13) from the device, edited where it lives
+            assert li.shape == (B, 13)
+            li[:, 0] += 0.05
+            li[:, 12] -= 0.05
+        elif e == "lidfa_after":
+            cs.LIDFa = np.full(B, 0.4)
+        elif e.startswith("nlayers"):
+            cs.nlayers = nl
+        else:
+            cs.lidf = lidf if e == "other_ab" else lidf[0]            # rows / one row for the whole batch
+            cs.nlayers = nl
+        for sensor in ("Sentinel2A-MSI", "TerraAqua-MODIS"):
+            sp = S.SPART(S.SoilParameters(*[P[:, i] for i in range(9, 15)]),
+                         S.LeafBiology(*[P[:, i] for i in range(7)], PROT=P[:, 7], CBC=P[:, 8]), cs,
+                         S.AtmosphericProperties(P[:, 22], P[:, 23], P[:, 24], Pa=P[:, 25]),
+                         S.Angles(P[:, 19], P[:, 20], P[:, 21]), sensor, 100)
+            table_edits.upcast_coefs(sp.sensorinfo)
+            with redirect_stdout(io.StringIO()):
+                res = sp.run(debug=True)
+                full = sp.run(debug=True, materialize=True)
+            for k in ("R_TOC", "R_TOA", "L_TOA", "rsoil"):
+                assert rel_err(res[k], fx[f"run/{e}/{sensor}/{k}"], 1e-6) < 1e-8, (e, sensor, k)
+                assert np.array_equal(res[k], full[k]), (e, sensor, k)
+            with np.errstate(all="ignore"):
+                o = oracle.spart_run(P, sensor, tables, pso="gl", full=True, lidf=lidf, nlayers=nl)
+            for k in ("rso", "rdo", "rsd", "rdd"):
+                assert rel_err(getattr(sp.canopyopt, k), o[k], 1e-3) < 1e-7, (e, sensor, k)
+
+
+@pytest.mark.gpu
+def test_canopy_state_through_the_c_abi(fx, oracle, tables):
+    """engine-level (the ctypes calls themselves): spart_sailh_batch(lidf_in, nlayers) with LIDFa / LIDFb NULL, spart_run_batch
+    with spart_materialize.lidf_in / .nlayers and params[16..17] NULL; bad nlayers are refused with SPART_ERR_INVALID."""
+    import torch
+    from spart_amd import get_engine
+    from test_oracle_golden import _edited
+    eng = get_engine("Sentinel2A-MSI", 0)
+    P = np.repeat(fx["run/P"], 40, axis=0)              # 360 rows: more than one workgroup of the prelude
+    lidf, nl = _edited(oracle, P[:, 15:19], "table_nlayers24", None)
+    lidf = lidf * (1 + 0.01 * np.sin(np.arange(P.shape[0]))[:, None])      # every row its own distribution
+    with np.errstate(all="ignore"):
+        o = oracle.spart_run(P, "Sentinel2A-MSI", tables, pso="gl", full=True, lidf=lidf, nlayers=nl)
+    cols = [P[:, i].copy() for i in range(27)]
+    cols[16] = cols[17] = None
+    for dtype, tol in (("float64", 1e-8), ("float32", 1e-4)):
+        res = eng.run(cols, dtype, canopy_lidf=lidf, nlayers=nl, materialize=["rso", "rdd"])
+        for k in ("R_TOC", "R_TOA", "L_TOA"):
+            assert rel_err(res[k].double().cpu().numpy(), o[k], 1e-6) < tol, (dtype, k)
+        for k in ("rso", "rdd"):
+            assert rel_err(res[k].double().cpu().numpy(), o[k], 1e-2) < (1e-7 if dtype == "float64" else 1e-4), (dtype, k)
+    # standalone SAILH entry point on the oracle's leaf / soil spectra
+    rho, tau = oracle.pad_leaf(o["leaf_refl"], o["leaf_tran"])
+    out = eng.sailh(rho, tau, oracle.pad_soil(o["soil_refl"]), [P[:, 15], None, None, P[:, 18]], [P[:, 19], P[:, 20], P[:, 21]],
+                    "float64", canopy_lidf=lidf, nlayers=nl)
+    for k, t in zip(("rso", "rdo", "rsd", "rdd"), out):
+        assert rel_err(t.cpu().numpy(), o[k], 1e-3) < 1e-8, k
+    # a default call is unchanged by the presence of the feature: nlayers = 60 given explicitly == not given
+    a = eng.run(cols[:16] + [P[:, 16], P[:, 17]] + cols[18:], "float64")
+    b = eng.run(cols[:16] + [P[:, 16], P[:, 17]] + cols[18:], "float64", nlayers=60)
+    assert all(torch.equal(a[k], b[k]) for k in ("R_TOC", "R_TOA", "L_TOA"))
+    with pytest.raises(ValueError):
+        eng.run(cols, "float64", canopy_lidf=lidf[:7])
+    with pytest.raises(ValueError, match="params\\[16\\]"):
+        eng.run(cols, "float64")                        # LIDFa missing without a lidf

@@ -44,6 +44,20 @@ def test_ctypes_signatures_cover_the_header(lib_path):
     _lib.load()
 
 
+def test_abi_version_matches_header_and_binding(lib_path):
+    """spart_abi_version() == SPART_ABI_VERSION of include/spart_hip.h == the ctypes binding's; the loader refuses a library
+    that reports another one (a build of an earlier round loaded through SPART_HIP_LIB would be called with shifted arguments)"""
+    from spart_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "spart_hip.h")).read()
+    v = int(re.search(r"#define\s+SPART_ABI_VERSION\s+(\d+)", hdr).group(1))
+    lib = ctypes.CDLL(lib_path)
+    assert lib.spart_abi_version() == v == _lib.ABI_VERSION
+    # the struct the binding hands over has the header's members, in order
+    members = re.search(r"typedef struct spart_materialize \{(.*?)\} spart_materialize;", re.sub(r"/\*.*?\*/", "", hdr, flags=re.S), flags=re.S).group(1)
+    names = re.findall(r"\*?\b([A-Za-z_0-9]+)\s*[,;]", members)
+    assert names == [f[0] for f in _lib.SpartMaterialize._fields_], names
+
+
 def test_code_object_targets_gfx950(lib_path):
     data = open(lib_path, "rb").read()
     assert b"amdgcn-amd-amdhsa--gfx950" in data

@@ -36,13 +36,18 @@ def tab(hm, tables):
     return t
 
 
-def run_chain(hm, tab, oracle, tables, P, sensor, dtype):
+def run_chain(hm, tab, oracle, tables, P, sensor, dtype, lidf_in=None, nlayers=0):
     P = np.ascontiguousarray(P, dtype=np.float64)
     B = P.shape[0]
     out = np.zeros((B, 2002, 10))
     atm = np.zeros((B, 16))
     lidf = np.zeros((B, 13))
-    hm.hm_bands(ctypes.c_int(dtype), ctypes.c_int64(B), dp(tab), dp(P), dp(out), dp(atm), dp(lidf))
+    if lidf_in is None and not nlayers:
+        hm.hm_bands(ctypes.c_int(dtype), ctypes.c_int64(B), dp(tab), dp(P), dp(out), dp(atm), dp(lidf))
+    else:
+        li = None if lidf_in is None else np.ascontiguousarray(np.broadcast_to(lidf_in, (B, 13)), dtype=np.float64)
+        hm.hm_bands_state(ctypes.c_int(dtype), ctypes.c_int64(B), dp(tab), dp(P), dp(li) if li is not None else None,
+                          ctypes.c_int(int(nlayers)), dp(out), dp(atm), dp(lidf))
     se = oracle.sensor_tables(tables, sensor)
     nb = se["coef"].shape[1]
     i0, i1, fr = oracle.interp_weights(se["wl_smac"])
@@ -113,6 +118,29 @@ def test_chain_vs_oracle_and_reference(hm, tab, oracle, tables, golden, dtype, t
         # sensor columns against the REAL reference's outputs
         for q, k in enumerate(("R_TOC", "R_TOA", "L_TOA")):
             assert rel_err(toa[:, :, q], g[f"{name}/{k}"][:64], 1e-3) < tol_col, (name, k)
+
+
+@pytest.mark.parametrize("dtype,tol", [(1, 1e-8), (0, 1e-4)])
+def test_canopy_state_arithmetic_against_the_reference(hm, tab, oracle, tables, golden, dtype, tol):
+    """The prelude with the caller's canopy.lidf / canopy.nlayers (sample_prelude_to<., true>: what k_prelude<., true> runs)
+    through the band arithmetic and SMAC, against the REAL reference's rows for every edit of canopy_edits.py."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import canopy_edits
+    from test_oracle_golden import _edited
+    g = golden["canopy_state"]
+    P = g["run/P"]
+    for e in ["none"] + list(canopy_edits.CANOPY_EDITS):
+        lidf, nl = _edited(oracle, P[:, 15:19], e, g["other_ab_lidf"])
+        state_lidf = None if e in ("none", "lidfa_after") or e.startswith("nlayers") else lidf
+        for sensor in ("Sentinel2A-MSI", "TerraAqua-MODIS"):
+            out, li, sm, toa = run_chain(hm, tab, oracle, tables, P, sensor, dtype, lidf_in=state_lidf, nlayers=0 if nl == 60 else nl)
+            if dtype == 1:
+                assert np.max(np.abs(li - lidf)) < 1e-13, e
+            for q, k in enumerate(("R_TOC", "R_TOA", "L_TOA")):
+                assert rel_err(toa[:, :, q], g[f"run/{e}/{sensor}/{k}"], 1e-6) < tol, (e, sensor, k)
+    # nlayers alone must move the result (the fixture's own statement), an un-normalised lidf must not be normalised
+    assert not np.array_equal(g["run/nlayers30/Sentinel2A-MSI/R_TOC"], g["run/none/Sentinel2A-MSI/R_TOC"])
 
 
 def test_hotspot_integrals_cover_small_q(hm, tab, oracle, tables):
