@@ -83,6 +83,17 @@ def _cpu_worker(job):
     return time.perf_counter() - t0
 
 
+def _config2_oracle(nrows):
+    """(cpu_baseline leg, checker only) the oracle's PROSPECT-5D on the first ``nrows`` rows of BASELINE config 2's workload"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import spart_oracle as O
+    from spart_amd import workloads
+    return O.prospect_5d(workloads.lhs_params(10_000, "leaf")[:nrows, :9], O.load_tables())
+
+
+CONFIG2_CHECK = {}        # filled by cpu_baseline(): expected refl / tran / kChlrel of config 2's first 256 rows
+
+
 def cpu_baseline(sensor, rows_per_core, seed):
     """The oracle (numpy port of the reference) timed on this box's host cores, bounded sample.  Runs BEFORE the
     GPU is initialised (worker processes are forked) and never touches it."""
@@ -100,6 +111,8 @@ def cpu_baseline(sensor, rows_per_core, seed):
         q0 = time.perf_counter()
         qbusy = pool.map(_cpu_worker, [(sensor, 4 * cores, seed, 4 * i, 4 * i + 4, "quad") for i in range(cores)])
         qdt = time.perf_counter() - q0
+        CONFIG2_CHECK["rows"] = 256
+        CONFIG2_CHECK["expected"] = pool.apply(_config2_oracle, (256,))
     return {"value": rows / dt, "unit": "spectra/s", "cores": cores, "kind": "port",
             "sample": f"{rows} rows of the same LHS workload, oracle/spart_oracle.py (vectorised numpy, closed-form E1 / "
                       f"Gauss-Legendre hot spot), {cores} processes, {dt:.1f} s wall ({sum(busy):.0f} s CPU)",
@@ -257,6 +270,15 @@ def extras(torch, args, dev):
                              "frac": by * 10_000 / sec / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_leaf": by,
                              "valu_tflop_eq": FLOP_EQ_PER_LEAF * 10_000 / sec / 1e12, "valu_peak_fp64": VALU_PEAK_TFLOPS["float64"],
                              "note": "whole call (prelude + k_prospect<double>) timed on the host, synchronised"}}
+    if CONFIG2_CHECK:
+        # the result of THE TIMED CALL against the oracle on the first 256 rows (computed in the cpu_baseline leg, before the GPU
+        # was initialised); tests/test_gpu_parity.py::test_config2_lhs_workload_all_rows checks all 10 000
+        got = eng0.prospect(cols, "float64")
+        n = CONFIG2_CHECK["rows"]
+        cfg["2"]["max_abs_vs_oracle"] = {k: float(abs(g[:n].cpu().numpy() - e).max())
+                                         for k, g, e in zip(("refl", "tran", "kChlrel"), got, CONFIG2_CHECK["expected"])}
+        cfg["2"]["max_abs_vs_oracle"]["rows"] = n
+        del got
     del cols
     # config 3: full SPART, 100k, Sentinel-2A, fp32 (and 125k = the per-GPU shard of config 4 cut in 8)
     for name, b in (("3", 100_000), ("4_shard_125k", 125_000)):

@@ -28,7 +28,7 @@ def tables(oracle):
 def golden():
     import numpy as np
     d = os.path.join(ROOT, "tests", "golden")
-    return {n: np.load(os.path.join(d, n + ".npz")) for n in ("prospect", "bsm", "sailh", "smac", "e2e", "rdry", "edge", "jpl", "grids", "s2_f64", "canopy_state")}
+    return {n: np.load(os.path.join(d, n + ".npz")) for n in ("prospect", "bsm", "sailh", "smac", "e2e", "rdry", "edge", "jpl", "grids", "s2_f64", "canopy_state", "config2")}
 
 
 def rel_err(a, b, floor=1e-6):

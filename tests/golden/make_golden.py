@@ -36,6 +36,8 @@ Files
                  TerraAqua-MODIS; and `stale/`: a second run() of ONE object after an edit of optipar / a leafbio field (the
                  reference's change tracker keeps its first answer, SPART.py:178-209) beside a fresh object's
                  (python tests/golden/make_golden.py canopy_state)
+  config2.npz    BASELINE config 2's own workload: the first 32 rows of workloads.lhs_params(10_000, "leaf") (7-D LHS, PROT = CBC = 0)
+                 through PROSPECT_5D: leaf (32,9) + refl / tran / kChlrel (32,2001)   (prospect_5d.py:117-246)
   edge.npz       128 rows of tools/edge_sweep.py's widened ranges with edge values (LAI 0 / 1e-4 / 10, dry soil, N = 1,
                  zero pigments, exact hot spot, grazing angles, PRO leaves), Sentinel2A: P + R_TOC / R_TOA / L_TOA
 """
@@ -108,6 +110,21 @@ def gen_prospect():
         out["refl"].append(lo.refl[:, 0]); out["tran"].append(lo.tran[:, 0]); out["kChlrel"].append(lo.kChlrel[:, 0])
     np.savez_compressed(os.path.join(HERE, "prospect.npz"), leaf=leaf, **{k: np.array(v) for k, v in out.items()})
     print("prospect", leaf.shape)
+
+
+def _leaf_row(r):
+    with redirect_stdout(io.StringIO()):
+        lo = PROSPECT_5D(LeafBiology(*r[:7], PROT=r[7], CBC=r[8]), SPART.load_optical_parameters())
+    return lo.refl[:, 0], lo.tran[:, 0], lo.kChlrel[:, 0]
+
+
+def gen_config2():
+    leaf = workloads.lhs_params(10_000, "leaf")[:32, :9]
+    with Pool(8) as pool:
+        res = pool.map(_leaf_row, list(leaf))
+    np.savez_compressed(os.path.join(HERE, "config2.npz"), leaf=leaf, refl=np.array([r[0] for r in res]),
+                        tran=np.array([r[1] for r in res]), kChlrel=np.array([r[2] for r in res]))
+    print("config2", leaf.shape)
 
 
 def gen_bsm():

@@ -51,6 +51,37 @@ def test_prospect_golden(golden, dtype, torch_mod):
     assert rel_err(kchl.cpu().numpy(), g["kChlrel"], fl) < tol
 
 
+def test_config2_lhs_workload_all_rows(golden, oracle, tables, torch_mod):
+    """BASELINE config 2 AS STATED: workloads.lhs_params(10_000, "leaf") (7-D Latin hypercube, PROT = CBC = 0, SURVEY.md section
+    8d) through spart_prospect_batch -- the call bench.py times as configs["2"].  float64: every one of the 3 x 10 000 x 2001
+    outputs against the oracle (refl, tran <= 2e-9 absolute, kChlrel <= 1e-9 relative) and the first 32 rows against the REAL
+    reference (config2.npz; 1.5e-7 = its own test precision, its QUADPACK E1 carries ~1e-8); float32 at 1e-4.
+    Match: prospect_5d.py:117-246."""
+    from spart_amd import get_engine, workloads
+    leaf = workloads.lhs_params(10_000, "leaf")[:, :9]
+    g = golden["config2"]
+    assert np.array_equal(leaf[:32], g["leaf"])
+    eng = get_engine(None, 0)
+    ref = oracle.prospect_5d(leaf, tables)
+    n0 = eng.calls["spart_prospect_batch"]
+    out = eng.prospect(list(leaf.T), "float64")
+    assert eng.calls["spart_prospect_batch"] == n0 + 1
+    for got, want, name in zip(out, ref, ("refl", "tran", "kChlrel")):
+        a = got.cpu().numpy()
+        assert a.shape == (10_000, 2001) and np.isfinite(a).all()
+        if name == "kChlrel":
+            assert rel_err(a, want, 1e-12) < 1e-9, name
+        else:
+            assert np.max(np.abs(a - want)) < 2e-9, name
+        assert np.max(np.abs(a[:32] - g[name])) < 1.5e-7, (name, "vs the reference")
+    out32 = eng.prospect(list(leaf.T), "float32")
+    for got, want, name in zip(out32, ref, ("refl", "tran", "kChlrel")):
+        assert rel_err(got.double().cpu().numpy(), want, 1e-2) < 1e-4, name
+    # any subset of the outputs gives the same numbers (the kernel skips the stores, nothing else)
+    only = eng.prospect(list(leaf.T), "float64", outputs=("tran",))
+    assert only[0] is None and only[2] is None and torch_mod.equal(only[1], out[1])
+
+
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_bsm_golden(golden, dtype, torch_mod):
     from spart_amd import get_engine

@@ -17,6 +17,19 @@ def test_prospect(oracle, tables, golden):
     assert np.isnan(g["refl"][13]).sum() == 11 and np.isnan(g["refl"]).sum() == 11
 
 
+def test_prospect_config2_workload_rows(oracle, tables, golden):
+    """BASELINE config 2's own generator (workloads.lhs_params(10_000, "leaf")): its first 32 rows through
+    the real reference (config2.npz) -- the rows the -m gpu test of the whole 10k workload is anchored on."""
+    from spart_amd_workloads import lhs_params
+    g = golden["config2"]
+    assert np.array_equal(lhs_params(10_000, "leaf")[:32, :9], g["leaf"])          # the fixture IS that workload
+    refl, tran, kchl = oracle.prospect_5d(g["leaf"], tables)
+    assert np.max(np.abs(refl - g["refl"])) < 5e-8 and np.max(np.abs(tran - g["tran"])) < 5e-8      # closed-form E1 vs QUADPACK
+    assert rel_err(kchl, g["kChlrel"], 1e-12) < 1e-12
+    refl, tran, _ = oracle.prospect_5d(g["leaf"][:4], tables, e1="quad")              # the reference's own E1 route: to rounding
+    assert np.max(np.abs(refl - g["refl"][:4])) < 1e-14 and np.max(np.abs(tran - g["tran"][:4])) < 1e-14
+
+
 def test_prospect_literal_quadrature_reproduces_nans(oracle, tables, golden):
     g = golden["prospect"]
     refl, tran, _ = oracle.prospect_5d(g["leaf"][13:14], tables, e1="quad")
