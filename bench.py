@@ -481,6 +481,89 @@ def mode_records(torch, args, dev):
     return rec
 
 
+def lut_records_multi_rank(torch, dist, args, dev, eng, rank, world, lut_local, row0, rows_per_rank, gathered_lut):
+    """N > 1: the LUT rows of SURVEY.md section 8(f) sharded over the ranks (spart_amd.sharding / spart_amd.lut), timed like the
+    headline (barrier + synchronise on both sides, MAX over ranks) and checked on rank 0 against the single-device search.
+    lut_local = this rank's R_TOC rows of the global table (its result of the timed steps), gathered_lut = the whole LUT on
+    rank 0 (from the steps' gather), None elsewhere.  Every rank returns; rank 0's dict goes into the line."""
+    import numpy as np
+    import spart_amd
+    from spart_amd import get_engine, sharding, workloads
+    nb = lut_local.shape[1]
+
+    def fence():
+        torch.cuda.synchronize()
+        dist.barrier()
+
+    def wall(fn, reps):
+        best, mine = 1e9, 1e9
+        for _ in range(reps):
+            fence()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            own = time.perf_counter() - t0
+            dist.barrier()
+            t = torch.tensor([time.perf_counter() - t0, own], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            if float(t[0]) < best:
+                best, mine = float(t[0]), own
+        return best, mine
+
+    rec = {}
+    # --- inversion: LUT row-sharded, M observations replicated, ONE all_gather of (cost bits, global row) per call
+    M = 65536
+    Bg = int(sum(rows_per_rank))
+    obs = torch.empty((M, nb), dtype=lut_local.dtype, device=dev)
+    if rank == 0:
+        g = torch.Generator(device=dev).manual_seed(3)
+        pick = torch.randint(0, Bg, (M,), generator=g, device=dev)
+        obs.copy_(gathered_lut[pick] * (1 + 0.02 * torch.randn((M, nb), generator=g, device=dev)))
+    dist.broadcast(obs, src=0)
+    eng0 = get_engine(None, dev.index)
+    comm = None if dist.get_backend() == "nccl" else "cpu"
+    search = lambda: sharding.lut_nearest_sharded(lut_local, row0, obs, eng0.lut_nearest, comm_device=comm)      # noqa: E731
+    idx, cost = search()
+    sec, own = wall(search, 5)
+    owns = [None] * world
+    dist.all_gather_object(owns, own * 1e3)
+    chk = None
+    if rank == 0:
+        si, sc = eng0.lut_nearest(gathered_lut, obs)
+        chk = {"winners_equal_to_single_device_search": int((idx.to(dev) == si).sum().item()),
+               "costs_bit_equal": int((cost.to(dev) == sc).sum().item()), "checked": M}
+    rec["lut_invert"] = dict({
+        "workload": f"spart_amd.sharding.lut_nearest_sharded: {Bg}-row LUT (R_TOC of the global table) ROW-SHARDED over {world} ranks x "
+                    f"{M} replicated observations, fp32: per-rank exact search + ONE all_gather of (cost, global row) -- 16 B x M per rank",
+        "value": Bg * M / sec, "unit": "row comparisons/s", "ms_per_step": sec * 1e3, "steps": 5, "observations_per_s": M / sec,
+        "ranks_seen": world, "rows_per_rank": list(rows_per_rank), "per_rank_ms": owns}, **(chk or {}))
+    # --- generation: every rank streams ITS block of the host table through its GPU into its own host arrays; no collective
+    P1 = workloads.lhs_params(args.batch, "full")
+    P8 = np.tile(P1, (8, 1))
+    spart_amd.generate_lut(P8[:1 << 18], args.sensor, prune=False, shard=True)
+    holder = {}
+
+    def gen():
+        holder["o"] = spart_amd.generate_lut(P8, args.sensor, prune=False, shard=True)
+    sec, own = wall(gen, 2)
+    o = holder["o"]
+    owns = [None] * world
+    dist.all_gather_object(owns, {"ms": own * 1e3, "rows": list(o.rows)})
+    # the block a rank produced == the rows the timed steps produced for the same parameters (rank-local check, then AND)
+    lo, hi = o.rows
+    ok = torch.tensor([1.0 if (o.total == P8.shape[0] and np.isfinite(o["R_TOC"]).all()) else 0.0], dtype=torch.float64, device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    rec["lut_generate"] = {
+        "workload": f"spart_amd.generate_lut(shard=True): {P8.shape[0]} spectra (the global table x 8) cut into {world} contiguous blocks, "
+                    f"{args.sensor}, fp32, each rank: pageable host table in -> its own host columns out, all 2162 bands evaluated; no collective "
+                    "on the data path; best of 2",
+        "value": P8.shape[0] / sec, "unit": "spectra/s", "ms_per_step": sec * 1e3, "ranks_seen": world,
+        "rows_per_rank": [r["rows"][1] - r["rows"][0] for r in owns], "per_rank_ms": [r["ms"] for r in owns],
+        "finite_on_every_rank": bool(ok.item() == 1.0),
+        "note": "PCIe-inclusive (every rank has its own link), reported beside the resident-input headline"}
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -630,6 +713,12 @@ def main():
                          "gather to rank 0 on its own (rank 0's clock); predicted_value = global batch / slowest rank's compute "
                          "= the rate with the gather fully hidden; gather_exposed_ms = ms_per_step - slowest compute")}
 
+    lut_rec = None
+    if world > 1 and not args.no_extras and args.dtype == "float32":
+        rows = diag["rows_per_rank"]
+        gathered = torch.cat([g[0, :n] for g, n in zip(gather_lists[0], rows)]) if rank == 0 else None
+        lut_rec = lut_records_multi_rank(torch, dist, args, dev, eng, rank, world, res[0][0, :B].clone(), lo if scaling == "strong" else sum(rows[:rank]),
+                                         rows, gathered)
     if rank == 0:
         ok = all(bool(torch.isfinite(r).all().item()) for r in res)
         if world > 1:
@@ -668,6 +757,8 @@ def main():
         line["cpu_baseline"] = cpu
         if diag is not None:
             line["multi_rank"] = diag
+        if lut_rec is not None:
+            line["configs"] = lut_rec
         if world == 1 and "columns_beside_bands" in line["roofline"]["stage_ms"]:
             ser = serial_stages(torch, args.sensor, dev_index, P, args.dtype)
             line["roofline"]["stage_ms_serial"] = ser

@@ -11,6 +11,6 @@ from .api import (BSM, PROSPECT_5D, SAILH, SMAC, SPART, Angles, AtmosphericOptic
 from .engine import Engine, get_engine  # noqa: F401
 from .tables import SENSORS  # noqa: F401
 from . import workloads  # noqa: F401
-from .lut import generate_lut, load_lut, lut_to_parquet  # noqa: F401
+from .lut import generate_lut, invert_lut, load_lut, lut_to_parquet  # noqa: F401
 
 __version__ = "0.1.0"

@@ -44,10 +44,62 @@ def _prefault(a):
         return False
 
 
+class LutBlock(dict):
+    """Result of generate_lut: the column arrays, with ``rows = (lo, hi)`` = the rows THIS process evaluated (the whole
+    table unless ``shard=True`` under a process group) and ``total`` = the table's row count.  Without ``path`` a sharded call
+    returns arrays holding only the rows lo..hi; with ``path`` the arrays are memmaps of the whole files."""
+    rows = (0, 0)
+    total = 0
+
+
+def _group_info(shard, group):
+    """(world, rank) of the process group a sharded call runs under; (1, 0) for a plain call"""
+    if not shard:
+        return 1, 0
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1, 0
+    return dist.get_world_size(group), dist.get_rank(group)
+
+
+def open_lut_files(path, files, world=1, rank=0, group=None):
+    """The .npy files of a LUT directory as writable memmaps shared by the ranks of a sharded generate_lut.
+    files: [(name, dtype, shape)].  Rank 0 creates them at their final size (and removes a manifest left over from an earlier
+    table: meta.json is what says "complete"); after ONE barrier the other ranks open the same files read-write; every rank
+    then writes only its own rows (single node: one page cache; on a network file system every rank must flush before the
+    closing barrier, which generate_lut does)."""
+    whole = None
+    if rank == 0:
+        os.makedirs(path, exist_ok=True)
+        stale = os.path.join(path, "meta.json")
+        if os.path.exists(stale):
+            os.remove(stale)
+        whole = {k: np.lib.format.open_memmap(os.path.join(path, k + ".npy"), mode="w+", dtype=dt_, shape=shp)
+                 for k, dt_, shp in files}
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier(group)                        # the files exist with their final size
+    if rank != 0:
+        whole = {k: np.lib.format.open_memmap(os.path.join(path, k + ".npy"), mode="r+") for k, _, _ in files}
+        for k, dt_, shp in files:
+            if whole[k].shape != tuple(shp) or whole[k].dtype != np.dtype(dt_):
+                raise RuntimeError(f"{path}/{k}.npy is {whole[k].shape} {whole[k].dtype}, expected {tuple(shp)} {np.dtype(dt_)}")
+    return whole
+
+
 def generate_lut(params, sensor, path=None, dtype="float32", chunk=1 << 18, device=None, prune=True, fault_threads=8,
-                 f32_bands=False):
+                 f32_bands=False, shard=False, group=None):
     """params: (B, 27) array-like on the HOST (numpy / memmap).  Returns dict of host arrays (np.memmap when
-    ``path`` is given).  ``prune=True`` (default: a LUT holds the sensor columns only) evaluates just the <= 2 nb bands those columns
+    ``path`` is given).
+
+    ``shard=True`` under an initialised torch.distributed process group (one process per GPU): the table is cut into
+    contiguous blocks of ceil(B / world) rows (sharding.shard_bounds) and every rank evaluates ITS block on its own device
+    and writes it at its own rows -- with ``path``, straight into the directory's R_TOC.npy / R_TOA.npy / L_TOA.npy /
+    params.npy (rank 0 creates the files, the other ranks open them read-write after ONE barrier; a second barrier, then rank
+    0 writes meta.json).  No result ever crosses ranks: there is no collective on the data path, and the directory is
+    byte-identical to a single-process run.  Without ``path`` every rank gets the arrays of its own block (LutBlock.rows).
+
+    ``prune=True`` (default: a LUT holds the sensor columns only) evaluates just the <= 2 nb bands those columns
     depend on -- bit-identical columns; ``prune=False`` also evaluates the other bands of every spectrum (band sums);
     ``dtype="float64", f32_bands=True`` gives float64 columns identical to the float64 mode's at the float32 mode's speed.
 
@@ -68,22 +120,29 @@ def generate_lut(params, sensor, path=None, dtype="float32", chunk=1 << 18, devi
 
     import torch
 
+    from .sharding import shard_bounds
     P = np.asarray(params) if not isinstance(params, np.memmap) else params
     if P.ndim != 2 or P.shape[1] != workloads.NPARAM:
         raise ValueError("params must be (B, 27)")
-    B = P.shape[0]
+    Btot = P.shape[0]
+    world, rank = _group_info(shard, group)
+    lo0, hi0 = shard_bounds(Btot, world, rank)
     eng = get_engine(sensor, device)
     nb = eng.nb
     npdt = np.float32 if dtype in ("float32", "fp32", "f32") else np.float64
     tdt = torch.float32 if npdt is np.float32 else torch.float64
     if path is not None:
-        os.makedirs(path, exist_ok=True)
-        out = {k: np.lib.format.open_memmap(os.path.join(path, k + ".npy"), mode="w+", dtype=npdt, shape=(B, nb))
-               for k in COLUMNS}
-        pm = np.lib.format.open_memmap(os.path.join(path, "params.npy"), mode="w+", dtype=np.float64, shape=P.shape)
+        whole = open_lut_files(path, [(k, npdt, (Btot, nb)) for k in COLUMNS] + [("params", np.float64, tuple(P.shape))],
+                               world, rank, group)
+        full_out = {k: whole[k] for k in COLUMNS}
+        out = {k: whole[k][lo0:hi0] for k in COLUMNS}          # this rank's rows of the shared files
+        pm = whole["params"][lo0:hi0]
     else:
-        out = {k: np.empty((B, nb), dtype=npdt) for k in COLUMNS}
+        full_out = None
+        out = {k: np.empty((hi0 - lo0, nb), dtype=npdt) for k in COLUMNS}
         pm = None
+    P = P[lo0:hi0]
+    B = hi0 - lo0
     chunk = int(max(1, min(chunk, max(B, 1))))
     dev = eng.device
     compute = torch.cuda.current_stream(dev)
@@ -181,15 +240,20 @@ def generate_lut(params, sensor, path=None, dtype="float32", chunk=1 << 18, devi
         if fpool is not None:
             fpool.shutdown(wait=True, cancel_futures=True)
     if path is not None:
-        for a in out.values():
+        for a in whole.values():
             a.flush()
-        pm.flush()
-        meta = {"sensor": sensor, "bands": list(eng.band_id), "wavelengths": [float(w) for w in eng.wl_smac],
-                "dtype": np.dtype(npdt).name, "rows": int(B), "param_names": workloads.PARAM_NAMES,
-                "columns": list(COLUMNS), "pruned": bool(prune)}
-        with open(os.path.join(path, "meta.json"), "w") as f:
-            json.dump(meta, f, indent=1)
-    return out
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier(group)                    # every rank's rows are in the files
+        if rank == 0:
+            meta = {"sensor": sensor, "bands": list(eng.band_id), "wavelengths": [float(w) for w in eng.wl_smac],
+                    "dtype": np.dtype(npdt).name, "rows": int(Btot), "param_names": workloads.PARAM_NAMES,
+                    "columns": list(COLUMNS), "pruned": bool(prune)}
+            with open(os.path.join(path, "meta.json"), "w") as f:
+                json.dump(meta, f, indent=1)
+    res = LutBlock(full_out if full_out is not None else out)
+    res.rows, res.total = (int(lo0), int(hi0)), int(Btot)
+    return res
 
 
 def load_lut(path, mmap=True):
@@ -199,6 +263,46 @@ def load_lut(path, mmap=True):
     mode = "r" if mmap else None
     cols = {k: np.load(os.path.join(path, k + ".npy"), mmap_mode=mode) for k in meta["columns"]}
     return meta, np.load(os.path.join(path, "params.npy"), mmap_mode=mode), cols
+
+
+def invert_lut(lut, obs, column="R_TOC", weights=None, dtype=None, shard=False, group=None, device=None, stats=False):
+    """Nearest LUT row per observed spectrum (spart_lut_nearest: exact argmin of the weighted squared distance, lowest index
+    on ties) over a LUT directory written by generate_lut (``lut`` = its path) or an in-memory (B, nb) array.
+
+    ``shard=True`` under a process group: every rank searches ITS contiguous block of rows (read from the directory's memmap:
+    only those rows are ever touched) and ONE all_gather of (cost, global row) per observation settles the winner
+    (sharding.lut_nearest_sharded); every rank returns the same (idx (M,) int64 numpy, cost (M,) numpy), equal bit for bit to
+    the single-process search.  ``obs`` must be the same on every rank."""
+    import torch
+    from .sharding import lut_nearest_sharded, shard_bounds
+    if isinstance(lut, (str, os.PathLike)):
+        meta, _, cols = load_lut(lut)
+        table = cols[column]
+        dtype = dtype or meta["dtype"]
+    else:
+        table = lut
+        dtype = dtype or ("float64" if np.asarray(lut[:1]).dtype == np.float64 else "float32")
+    world, rank = _group_info(shard, group)
+    lo, hi = shard_bounds(table.shape[0], world, rank)
+    eng = get_engine(None, device)
+    td = torch.float32 if dtype in ("float32", "fp32", "f32") else torch.float64
+    local = torch.as_tensor(np.ascontiguousarray(table[lo:hi])).to(device=eng.device, dtype=td)
+    o = torch.as_tensor(np.asarray(obs)).to(device=eng.device, dtype=td)
+    info = {}
+
+    def nearest(l, ob):
+        r = eng.lut_nearest(l, ob, weights=weights, dtype=dtype, stats=stats)
+        if stats:
+            info.update(r[2])
+        return r[0], r[1]
+    comm = None
+    if world > 1:
+        import torch.distributed as dist
+        if dist.get_backend(group) != "nccl":          # gloo moves host tensors: the (M, 2) winners travel through the host
+            comm = "cpu"
+    idx, cost = lut_nearest_sharded(local, lo, o, nearest, group if world > 1 else None, comm_device=comm)
+    out = (idx.cpu().numpy(), cost.cpu().numpy())
+    return out + (dict(info, rows=(lo, hi)),) if stats else out
 
 
 def lut_to_parquet(path, parquet_path, compression="gzip"):

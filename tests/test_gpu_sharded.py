@@ -107,6 +107,90 @@ def test_two_gloo_ranks_with_the_hip_evaluator_match_single_rank():
     assert same                                                    # shards are independent: bit-identical to one rank
 
 
+def _lut_rank(rank, world, port, path, B, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, os.path.join(ROOT, "spart-python_amd"))
+    import torch
+    import torch.distributed as dist
+    import spart_amd
+    from spart_amd import workloads
+    torch.cuda.set_device(0)                                        # the ranks share the one GPU
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    P = workloads.lhs_params(B, "full", seed=21)
+    blk = spart_amd.generate_lut(P, "Sentinel2A-MSI", path=path, chunk=4096, shard=True)      # several chunks per rank
+    mem = spart_amd.generate_lut(P, "Sentinel2A-MSI", chunk=4096, shard=True)                 # in memory: this rank's block only
+    lo, hi = blk.rows
+    ok_mem = mem.rows == (lo, hi) and all(mem[k].shape == (hi - lo, 13) and np.array_equal(mem[k], np.asarray(blk[k][lo:hi]))
+                                          for k in ("R_TOC", "R_TOA", "L_TOA"))
+    # observations: noisy copies of LUT rows + exact copies (ties cannot occur in an LHS table: add a duplicate row pair by
+    # searching TWO stacked copies of the column below)
+    meta, _, cols = spart_amd.load_lut(path)
+    lut = np.asarray(cols["R_TOC"])
+    rng = np.random.default_rng(4)
+    obs = (lut[rng.integers(0, B, 300)] * (1 + 0.02 * rng.standard_normal((300, 13)))).astype(np.float32)
+    obs[:5] = lut[[0, B - 1, B // 2, 7, B // 3]]
+    idx, cost, st = spart_amd.invert_lut(path, obs, shard=True, stats=True)
+    w = np.linspace(0.5, 2.0, 13).astype(np.float32)
+    idx_w, cost_w = spart_amd.invert_lut(path, obs, weights=w, shard=True)
+    twice = np.concatenate([lut, lut])                              # every row twice: the copy in the lower half must win
+    idx_t, cost_t = spart_amd.invert_lut(twice, obs, shard=True)
+    q.put((rank, (lo, hi), ok_mem, idx, cost, idx_w, cost_w, idx_t, cost_t, st["rows"], meta["rows"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_lut_rows_sharded_over_gloo_ranks_match_single_rank(world, tmp_path):
+    """SURVEY 8(e) x (f3)/(f4): generate_lut(shard=True) -- every rank evaluates and writes its own contiguous block of the
+    directory's .npy files, no gather -- and invert_lut(shard=True) -- local exact argmin + ONE all_gather of (cost, global row)
+    -- with 2 and 3 ranks (ragged blocks) on the one GPU under gloo: the directory is byte-identical to a single-process
+    run's, winners and costs equal the single-process search (and a brute force of the defined cost), lowest row on ties."""
+    import torch.multiprocessing as mp
+    import spart_amd
+    from spart_amd import workloads
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from lut_brute_force import brute_force_numpy
+    B = 30_001
+    P = workloads.lhs_params(B, "full", seed=21)
+    single = str(tmp_path / "single")
+    spart_amd.generate_lut(P, "Sentinel2A-MSI", path=single, chunk=4096)
+    path = str(tmp_path / "sharded")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_lut_rank, args=(r, world, port, path, B, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=600) for _ in range(world)), key=lambda g: g[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    per = -(-B // world)
+    assert [g[1] for g in got] == [(min(B, r * per), min(B, (r + 1) * per)) for r in range(world)]
+    assert all(g[2] for g in got) and all(g[9] == g[1] and g[10] == B for g in got)
+    for f in ("R_TOC.npy", "R_TOA.npy", "L_TOA.npy", "params.npy", "meta.json"):
+        assert open(os.path.join(path, f), "rb").read() == open(os.path.join(single, f), "rb").read(), f
+    # inversion: the same answer on every rank, equal to the single-process call and to the brute force
+    _, _, cols = spart_amd.load_lut(single)
+    lut = np.asarray(cols["R_TOC"])
+    obs_idx, obs_cost = got[0][3], got[0][4]
+    for g in got[1:]:
+        for a, b in zip(g[3:9], got[0][3:9]):
+            assert np.array_equal(a, b)
+    rng = np.random.default_rng(4)
+    obs = (lut[rng.integers(0, B, 300)] * (1 + 0.02 * rng.standard_normal((300, 13)))).astype(np.float32)
+    obs[:5] = lut[[0, B - 1, B // 2, 7, B // 3]]
+    si, sc = spart_amd.invert_lut(single, obs)
+    assert np.array_equal(obs_idx, si) and np.array_equal(obs_cost, sc)
+    bi, bc = brute_force_numpy(lut, obs)
+    assert np.array_equal(obs_idx, bi) and np.array_equal(obs_cost, bc)
+    assert obs_idx[:5].tolist() == [0, B - 1, B // 2, 7, B // 3] and (obs_cost[:5] == 0).all()
+    w = np.linspace(0.5, 2.0, 13).astype(np.float32)
+    bi, bc = brute_force_numpy(lut, obs, w)
+    assert np.array_equal(got[0][5], bi) and np.array_equal(got[0][6], bc)
+    assert np.array_equal(got[0][7], obs_idx) and np.array_equal(got[0][8], obs_cost)      # duplicates: the lower copy wins
+
+
 def test_bench_under_the_drivers_multi_rank_invocation():
     """The driver's exact N > 1 command line -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
     127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W` -- as a fresh child process, with two ranks sharing
@@ -117,8 +201,8 @@ def test_bench_under_the_drivers_multi_rank_invocation():
     import json
     import subprocess
     env = dict(os.environ, SPART_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    common = ["--batch", "200000", "--steps", "3", "--warmup", "1", "--cpu-rows", "0", "--no-extras"]
-    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", *common], env=env, capture_output=True,
+    common = ["--batch", "200000", "--steps", "3", "--warmup", "1", "--cpu-rows", "0"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", *common, "--no-extras"], env=env, capture_output=True,
                          text=True, timeout=600, cwd=ROOT)
     assert one.returncode == 0, one.stderr[-2000:]
     l1 = [json.loads(l) for l in one.stdout.splitlines() if l.startswith("{")]
@@ -147,3 +231,10 @@ def test_bench_under_the_drivers_multi_rank_invocation():
         assert m["gather_ms"] > 0 and np.isfinite(m["predicted_value"]) and m["predicted_value"] > 0
         assert max(m["per_rank_ms"]) <= b["ms_per_step"] * 1.001          # ms_per_step IS the maximum over the ranks' own clocks
         assert abs(m["gather_exposed_ms"] - (b["ms_per_step"] - max(m["per_rank_compute_ms"]))) < 1e-9
+        # the LUT rows sharded over the same ranks (SURVEY 8e x 8f): generation without any collective, inversion with one
+        # all_gather of the per-rank winners -- every rank took part, and rank 0 re-did the search on one device
+        li, lg = b["configs"]["lut_invert"], b["configs"]["lut_generate"]
+        assert li["ranks_seen"] == world and li["rows_per_rank"] == rows and len(li["per_rank_ms"]) == world
+        assert li["winners_equal_to_single_device_search"] == li["checked"] == li["costs_bit_equal"] == 65536
+        assert lg["ranks_seen"] == world and sum(lg["rows_per_rank"]) == 8 * 200000 and lg["finite_on_every_rank"] is True
+        assert lg["value"] > 0 and li["value"] > 0
