@@ -15,8 +15,11 @@ from . import tables as _tables
 from .tables import load_ET_parameters, load_optical_parameters, load_sensor_info  # noqa: F401 (re-exported)
 
 
+_PLAIN = (float, int, np.float64, np.float32, np.int64, np.int32)
+
+
 def _is_scalar(*vals):
-    return all(np.ndim(v) == 0 for v in vals)
+    return all(type(v) in _PLAIN or np.ndim(v) == 0 for v in vals)
 
 
 def _np(t):
@@ -474,8 +477,8 @@ class BatchResult(dict):
 
 class SPART:
     """SPART.py:35-269.  Stateless per call: every run() evaluates all stages for the current
-    parameter objects, which equals what a FRESH reference object returns (the reference's
-    per-object change tracker is not reproduced)."""
+    parameter objects and tables, which equals what a FRESH reference object returns.  The reference's per-object change
+    tracker (stale cached stages after an edit no setter sees, SPART.py:178-209) is deliberately NOT reproduced: see run()."""
 
     def __init__(self, soilpar, leafbio, canopy, atm, angles, sensor, DOY, dtype="float64", device=None):
         self.soilpar = soilpar
@@ -488,7 +491,8 @@ class SPART:
         self.device = device
         self.spectral = SpectralBands()
         # SPART.py:93-95: public, mutable, and READ BY run() -- an edit of any of the three dicts (or of an array inside
-        # one) changes the next run(), exactly as in the reference
+        # one) made before the object's FIRST run() changes it exactly as in the reference; later edits also take effect
+        # here, while the reference keeps its cached stages (see run(): stateless by design)
         self.optipar = load_optical_parameters()
         self.ETpar = load_ET_parameters()
         self.sensor = sensor                             # (property: loads sensorinfo; FileNotFoundError for unknown sensors, SPART.py:421-423)
@@ -510,6 +514,54 @@ class SPART:
 
     _LAZY = ("atmopt", "leafopt", "soilopt", "canopyopt")
 
+    def _engine(self):
+        """The device context whose tables have the CONTENT of self.optipar / self.ETpar / self.sensorinfo right now
+        (SPART.py:181-184, 192, 202, 216, 228).  The three dicts are hashed as they are on every call (engine.raw_digest: ~30 us
+        with xxhash); the digest -> (engine, band centres, band ids) resolved by the validating slow path is remembered per
+        object, so a loop of run() calls pays for the conversion and validation of the tables once per distinct content."""
+        key = (_engine.raw_digest(self.optipar, self.ETpar, self.sensorinfo), self.device)
+        memo = self.__dict__.setdefault("_engine_memo", {})
+        hit = memo.get(key)
+        if hit is None:
+            import pandas as pd
+            eng = _engine.get_engine(self.sensor, self.device, optical_params=self.optipar, et_params=self.ETpar,
+                                     sensor_info=self.sensorinfo)
+            wl = np.array(self.sensorinfo["wl_smac"].T[0], copy=True)
+            bands = self.sensorinfo["band_id_smac"]
+            if len(memo) >= 8:
+                memo.pop(next(iter(memo)))
+            hit = memo[key] = (eng, wl, bands, pd.Index(wl), np.array(list(bands), dtype=object))
+        return hit
+
+    def _run_scalar(self, eng, cols, th, ncol, debug, clidf, nlay):
+        """One sample, host scalars in, host columns out: ONE pinned (29,) block up, ONE pinned (ncol, nb) block down, both
+        preallocated per object (no per-call tensor allocation), one spart_run_batch in between."""
+        import torch
+        key = (id(eng), self.dtype, len(ncol))
+        io = self.__dict__.setdefault("_scalar_io", {})
+        b = io.get(key)
+        if b is None:
+            td = torch.float32 if _engine.DTYPES[self.dtype] == 0 else torch.float64
+            hin = torch.empty((29, 1), dtype=torch.float64).pin_memory()
+            hout = torch.empty((len(ncol), 1, eng.nb), dtype=td).pin_memory()
+            io.clear()                                          # (one staging pair per object: the last configuration's)
+            b = io[key] = dict(hin=hin, hin_np=hin.numpy()[:, 0], hout=hout, hout_np=hout.numpy()[:, 0, :],
+                               din=torch.empty((29, 1), dtype=torch.float64, device=eng.device),
+                               dout=torch.empty((len(ncol), 1, eng.nb), dtype=td, device=eng.device))
+        vals = b["hin_np"]
+        for i, c in enumerate(cols):
+            vals[i] = 0.0 if c is None else c                   # (None: LIDFa / LIDFb with a given lidf, B / lat / lon with rdry)
+        vals[27], vals[28] = th
+        b["din"].copy_(b["hin"], non_blocking=True)
+        din, dout = b["din"], b["dout"]
+        fields = ["La", "rsoil"] if debug else ["La"]
+        eng.run(din[:27], self.dtype, rho_thermal=din[27], tau_thermal=din[28], materialize=fields, prune=True,
+                out={k: dout[i] for i, k in enumerate(ncol)}, canopy_lidf=clidf, nlayers=nlay)
+        b["hout"].copy_(dout, non_blocking=True)
+        torch.cuda.current_stream(eng.device).synchronize()
+        host = b["hout_np"].copy()                              # (the staging block is reused by the next call)
+        return {k: host[i:i + 1] for i, k in enumerate(ncol)}
+
     def run(self, debug=False, materialize=False):
         """Returns the reference's DataFrame (columns Band, L_TOA, R_TOA, R_TOC indexed by band
         centre) for scalar parameters, a BatchResult of (B, nb) arrays otherwise.
@@ -519,40 +571,48 @@ class SPART:
         object carries after run() (SPART.py:66-81, 197, 209, 214, 229) -- ``atmopt`` and the full-spectrum
         ``leafopt / soilopt / canopyopt`` -- are computed on FIRST ACCESS from the parameters of this run (one
         spart_smac_batch, resp. one materialising spart_run_batch, cached); ``materialize=True`` computes the spectra
-        eagerly in the same call instead."""
+        eagerly in the same call instead.
+
+        STATELESS, deliberately unlike upstream: every run() evaluates all stages from the CURRENT parameter objects and the
+        CURRENT optipar / ETpar / sensorinfo, i.e. it returns what a FRESH reference object built from them returns.  The
+        reference caches soilopt / leafopt / _La / atmopt behind its _tracker flags (SPART.py:178-209, 226-232), which only the
+        property setters flip: after a first run(), ``sp.leafbio.Cab = 60`` or ``sp.optipar["Kab"] *= 1.1`` change NOTHING
+        upstream until e.g. ``sp.leafbio = sp.leafbio`` is assigned (tests/golden/canopy_state.npz `stale/` pins that).  Here
+        both edits take effect on the next run()."""
         import pandas as pd
         _pro_warning(self.leafbio)
-        # the device context whose tables have the CONTENT of self.optipar / self.ETpar / self.sensorinfo right now
-        # (SPART.py:181-184, 192, 202, 216, 228); the unmodified dicts resolve to the packaged sensor's engine
-        eng = _engine.get_engine(self.sensor, self.device, optical_params=self.optipar, et_params=self.ETpar,
-                                 sensor_info=self.sensorinfo)
+        eng, wl, bands, wl_index, bands_arr = self._engine()
         cols = self._columns()
-        fields = ["La"]
-        if debug:
-            fields.append("rsoil")
-        if materialize:
-            fields += _SPECTRA
         rdry = self.soilpar.rdry if getattr(self.soilpar, "rdry_set", False) else None
         th = (self.leafbio.rho_thermal, self.leafbio.tau_thermal)
         _, clidf, nlay = _canopy_state(self.canopy)      # canopy.lidf / canopy.nlayers as SAILH reads them (sailh.py:48, 51)
-        # the (B, nb) results share ONE device block, so that they come back in one device-to-host copy
-        import torch
         ncol = ["R_TOC", "R_TOA", "L_TOA", "La"] + (["rsoil"] if debug else [])
-        B = max([int(np.size(c)) if not torch.is_tensor(c) else c.numel() for c in cols if c is not None] + [1])
-        if rdry is not None:
-            r0 = rdry if torch.is_tensor(rdry) else np.asarray(rdry)
-            B = max(B, 1 if (r0.ndim == 1 or (r0.ndim == 2 and r0.shape[1] == 1)) else r0.shape[0])
-        if clidf is not None and np.ndim(clidf) == 2 and np.shape(clidf)[1] != 1:
-            B = max(B, int(np.shape(clidf)[0]))
-        td = torch.float32 if _engine.DTYPES[self.dtype] == 0 else torch.float64
-        blk = torch.empty((len(ncol), B, eng.nb), dtype=td, device=eng.device)
-        res = eng.run(cols, self.dtype, rho_thermal=th[0], tau_thermal=th[1], materialize=fields, rdry=rdry,
-                      prune=not materialize, out={k: blk[i] for i, k in enumerate(ncol)}, canopy_lidf=clidf, nlayers=nlay)
-        host = _np(blk)
-        out = {k: (host[ncol.index(k)] if k in ncol else _np(v)) for k, v in res.items()}
-        scalar = _is_scalar(*[c for c in cols if c is not None]) and out["R_TOC"].shape[0] == 1
-        wl = self.sensorinfo["wl_smac"].T[0]
-        bands = self.sensorinfo["band_id_smac"]
+        import torch
+        fast = (not materialize and rdry is None and _is_scalar(*[c for c in cols if c is not None], *th)
+                and not any(torch.is_tensor(c) for c in cols) and (clidf is None or np.size(clidf) == 13))
+        if fast:
+            out = self._run_scalar(eng, cols, th, ncol, debug, clidf, nlay)
+            scalar = True
+        else:
+            fields = ["La"]
+            if debug:
+                fields.append("rsoil")
+            if materialize:
+                fields += _SPECTRA
+            # the (B, nb) results share ONE device block, so that they come back in one device-to-host copy
+            B = max([int(np.size(c)) if not torch.is_tensor(c) else c.numel() for c in cols if c is not None] + [1])
+            if rdry is not None:
+                r0 = rdry if torch.is_tensor(rdry) else np.asarray(rdry)
+                B = max(B, 1 if (r0.ndim == 1 or (r0.ndim == 2 and r0.shape[1] == 1)) else r0.shape[0])
+            if clidf is not None and np.ndim(clidf) == 2 and np.shape(clidf)[1] != 1:
+                B = max(B, int(np.shape(clidf)[0]))
+            td = torch.float32 if _engine.DTYPES[self.dtype] == 0 else torch.float64
+            blk = torch.empty((len(ncol), B, eng.nb), dtype=td, device=eng.device)
+            res = eng.run(cols, self.dtype, rho_thermal=th[0], tau_thermal=th[1], materialize=fields, rdry=rdry,
+                          prune=not materialize, out={k: blk[i] for i, k in enumerate(ncol)}, canopy_lidf=clidf, nlayers=nlay)
+            host = _np(blk)
+            out = {k: (host[ncol.index(k)] if k in ncol else _np(v)) for k, v in res.items()}
+            scalar = _is_scalar(*[c for c in cols if c is not None]) and out["R_TOC"].shape[0] == 1
         # attributes documented at SPART.py:66-81
         self.R_TOC, self.R_TOA, self.L_TOA, self._La = out["R_TOC"], out["R_TOA"], out["L_TOA"], out["La"]
         # what the lazy attributes are evaluated from: COPIES of the parameters and the dtype of THIS run (the reference sets the
@@ -567,11 +627,10 @@ class SPART:
             self._set_spectra(out, scalar)
         if not scalar:
             return BatchResult(out, wl, bands)
-        table = pd.DataFrame(zip(bands, out["L_TOA"][0], out["R_TOA"][0], out["R_TOC"][0]), index=wl,
-                             columns=["Band", "L_TOA", "R_TOA", "R_TOC"])      # SPART.py:256-260
+        data = {"Band": bands_arr.copy(), "L_TOA": out["L_TOA"][0], "R_TOA": out["R_TOA"][0], "R_TOC": out["R_TOC"][0]}   # SPART.py:256-260
         if debug:
-            table["rsoil"] = out["rsoil"][0]                                    # SPART.py:262-267
-        return table
+            data["rsoil"] = out["rsoil"][0]                                     # SPART.py:262-267
+        return pd.DataFrame(data, index=wl_index, copy=False)
 
     def _set_spectra(self, out, scalar):
         col = (lambda a: a[0][:, None].copy()) if scalar else (lambda a: a)

@@ -3,6 +3,7 @@
 compute call goes through the C ABI (include/spart_hip.h)."""
 import collections
 import ctypes
+import threading
 
 import numpy as np
 
@@ -44,15 +45,17 @@ OPTICAL_KEYS = ("nr", "Kab", "Kca", "Kdm", "Kw", "Ks", "Kant", "cbc", "prot", "G
 SENSOR_KEYS = ("wl_smac", "SMAC_coef", "wl_srf_smac", "p_srf_smac")               # SPART.py:216, 228, 376-377
 
 try:                                         # (the digest is a cache key, not a security boundary)
-    import xxhash as _xx
+    import xxhash as _xx                     # optional dependency: ~20 us per 230 KB of tables
 
     def _hasher():
         return _xx.xxh3_128()
+    HASHER = "xxhash.xxh3_128"
 except ImportError:                          # pragma: no cover
-    import hashlib as _hl
+    import hashlib as _hl                    # without xxhash: blake2b, ~0.2 ms per call of a scalar SPART.run() (README states both)
 
     def _hasher():
-        return _hl.sha1()
+        return _hl.blake2b(digest_size=16)
+    HASHER = "hashlib.blake2b"
 
 
 def _digest(arrays):
@@ -61,6 +64,60 @@ def _digest(arrays):
         h.update(np.asarray(a.shape, dtype=np.int64).tobytes())
         h.update(a.data)
     return h.hexdigest()
+
+
+def _raw_update(h, v):
+    """feed one table value into the hasher WITHOUT converting it: dtype + shape + raw bytes (float64 C-contiguous arrays -- the
+    packaged tables -- are hashed in place; anything else through one contiguous copy)"""
+    a = v if isinstance(v, np.ndarray) else np.asarray(v)
+    if a.dtype == object:
+        h.update(repr(a.tolist()).encode())
+        return
+    if not a.flags.c_contiguous:
+        a = np.ascontiguousarray(a)
+    h.update(a.dtype.str.encode())
+    h.update(np.asarray(a.shape, dtype=np.int64).tobytes())
+    h.update(a.data if a.ndim else a.tobytes())
+
+
+def raw_digest(optical_params, et_params, sensor_info):
+    """Digest of the three reference-style dicts AS THEY ARE (no float64 conversion, no validation): the keys the context is
+    built from, in a fixed order.  Equal raw content -> equal converted tables -> the same engine, so a caller (SPART.run) may
+    key a small cache on it and skip optical_block / sensor_block on the hot path; any edit of a dict or of an array in place
+    changes it.  A missing key hashes as such (the slow path then raises the reference's KeyError).
+    C-contiguous arrays go to the hasher through the buffer protocol as they are (~0.4 us each + 20 us for the 230 KB); their
+    dtypes and sizes are hashed once at the end."""
+    h = _hasher()
+    up = h.update
+    meta = []
+    add = meta.append
+    nd = np.ndarray
+
+    def feed(d, k):
+        v = d.get(k) if d is not None else None
+        if v is None:
+            up(b"\0missing:" + k.encode())
+        elif type(v) is nd and v.flags.c_contiguous and v.dtype != object:
+            up(v)
+            add(v.dtype.num)
+            add(v.size)
+        else:
+            _raw_update(h, v)
+
+    for k in OPTICAL_KEYS:
+        feed(optical_params, k)
+    feed(et_params, "Ea")
+    feed(et_params, "wl_Ea")
+    for k in ("wl_smac", "wl_srf_smac", "p_srf_smac", "band_id_smac"):
+        feed(sensor_info, k)
+    coefs = sensor_info.get("SMAC_coef") if sensor_info is not None else None
+    if coefs is None:
+        up(b"\0nocoef")
+    else:
+        for n in tables.COEF_NAMES:
+            feed(coefs, n)
+    up(np.array(meta, dtype=np.int64))
+    return h.digest()
 
 
 def optical_block(optical_params=None, et_params=None, need=OPTICAL_KEYS):
@@ -411,12 +468,15 @@ class Engine:
         torch = self.torch
         dt = DTYPES[dtype]
         td = self._tdtype(dt)
+        col_ptrs = None
         if torch.is_tensor(params) and params.dim() == 2:
             if params.shape[0] != _lib.NPARAM:
                 raise ValueError("params must be (27, B)")
             P = params.to(device=self.device, dtype=torch.float64).contiguous()
             B = P.shape[1]
-            cols = [P[i] for i in range(_lib.NPARAM)]
+            cols = None
+            base = P.data_ptr()                     # row i of the contiguous block: no 27 tensor views, no 27 data_ptr() calls
+            col_ptrs = (_lib.vp * _lib.NPARAM)(*[base + 8 * B * i for i in range(_lib.NPARAM)])
         else:
             plist = [0.0 if (p is None and (rdry is not None or (canopy_lidf is not None and i in (16, 17)))) else p
                      for i, p in enumerate(params)]
@@ -482,7 +542,8 @@ class Engine:
         else:
             ws, wsn = self._workspace(dt, B)
         self.calls["spart_run_batch"] += 1
-        rc = self.lib.spart_run_batch(self.ctx, dt, B, self._ptrs(cols), th[0].data_ptr() if th[0] is not None else None,
+        rc = self.lib.spart_run_batch(self.ctx, dt, B, col_ptrs if col_ptrs is not None else self._ptrs(cols),
+                                      th[0].data_ptr() if th[0] is not None else None,
                                       th[1].data_ptr() if th[1] is not None else None, res["R_TOC"].data_ptr(),
                                       res["R_TOA"].data_ptr(), res["L_TOA"].data_ptr(),
                                       ctypes.byref(mat) if mat is not None else None, ws, wsn, self._stream())
@@ -587,6 +648,7 @@ class Engine:
         return out
 
 
+_cache_lock = threading.RLock()   # guards the three caches below (contexts are thread-safe; so is finding one)
 _engines = {}            # (sensor name, device) -> Engine built from the packaged tables: no hashing on this path
 _by_content = {}         # (table digest, sensor digest | None, device) -> Engine, least recently used last out
 _packaged_digest = {}    # memo: digests of the packaged tables ("optical") and sensors (name)
@@ -608,6 +670,11 @@ def get_engine(sensor=None, device=None, optical_params=None, et_params=None, se
     if device is None:
         device = torch.cuda.current_device()
     device = int(device)
+    with _cache_lock:
+        return _get_engine_locked(sensor, device, optical_params, et_params, sensor_info, need)
+
+
+def _get_engine_locked(sensor, device, optical_params, et_params, sensor_info, need):
     if optical_params is None and et_params is None and sensor_info is None:
         key = (sensor, device)
         if key not in _engines:

@@ -286,7 +286,7 @@ def invert_lut(lut, obs, column="R_TOC", weights=None, dtype=None, shard=False, 
     lo, hi = shard_bounds(table.shape[0], world, rank)
     eng = get_engine(None, device)
     td = torch.float32 if dtype in ("float32", "fp32", "f32") else torch.float64
-    local = torch.as_tensor(np.ascontiguousarray(table[lo:hi])).to(device=eng.device, dtype=td)
+    local = torch.as_tensor(np.array(table[lo:hi])).to(device=eng.device, dtype=td)      # (a copy: memmaps opened read-only)
     o = torch.as_tensor(np.asarray(obs)).to(device=eng.device, dtype=td)
     info = {}
 

@@ -225,3 +225,31 @@ def test_canopy_state_through_the_c_abi(fx, oracle, tables):
         eng.run(cols, "float64", canopy_lidf=lidf[:7])
     with pytest.raises(ValueError, match="params\\[16\\]"):
         eng.run(cols, "float64")                        # LIDFa missing without a lidf
+
+
+@pytest.mark.gpu
+def test_second_run_is_stateless_where_the_reference_is_stale(fx):
+    """the reference caches soilopt / leafopt / atmopt behind tracker flags that only its property setters flip
+    (SPART.py:178-209), so a second run() after ``sp.optipar["Kab"] *= 1.1`` or ``sp.leafbio.Cab = 60`` returns its FIRST
+    answer (fixture `stale/.../second == first`).  This package is stateless by design: the second run() returns what a
+    FRESH reference object built after the same edit returns (fixture `fresh`).  Documented in SPART.run / README."""
+    import SPART as S
+    from spart_amd_workloads import default_row
+    d = default_row()[0]
+    edits = {"optipar_kab": lambda sp: sp.optipar.__setitem__("Kab", np.asarray(sp.optipar["Kab"], dtype=np.float64) * 1.1),
+             "leafbio_cab": lambda sp: setattr(sp.leafbio, "Cab", 60.0)}
+    for tag, edit in edits.items():
+        sp = S.SPART(S.SoilParameters(*d[9:15]), S.LeafBiology(*d[0:7]), S.CanopyStructure(*d[15:19]),
+                     S.AtmosphericProperties(d[22], d[23], d[24], Pa=d[25]), S.Angles(*d[19:22]), "Sentinel2A-MSI", 100)
+        table_edits.upcast_coefs(sp.sensorinfo)
+        first = sp.run()
+        keep = first.copy()
+        edit(sp)
+        second = sp.run()
+        p = f"stale/Sentinel2A-MSI/{tag}/"
+        for k in ("R_TOC", "R_TOA", "L_TOA"):
+            assert rel_err(first[k].to_numpy(), fx[p + "first/" + k], 1e-6) < 1e-7, (tag, k)
+            assert rel_err(second[k].to_numpy(), fx[p + "fresh/" + k], 1e-6) < 1e-7, (tag, k)       # NOT the reference's `second`
+        assert first.equals(keep)                        # an earlier result is not touched by a later run (staging is reused)
+        assert list(second.columns) == ["Band", "L_TOA", "R_TOA", "R_TOC"] and list(second.index)[:2] == [445, 520]
+        assert second["Band"].dtype == object and second["R_TOC"].dtype == np.float64
