@@ -24,7 +24,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "spart-python_amd"))
 
-PROFILE_TAGS = ("r5", "r4", "r3", "r2")   # profiles/<tag>_counters_<what>.json: the committed rocprofv3 PMC passes (tools/ingest_profiles.py), newest first
+PROFILE_TAGS = ("r6", "r5", "r4", "r3", "r2")   # profiles/<tag>_counters_<what>.json: the committed rocprofv3 PMC passes (tools/ingest_profiles.py), newest first
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_TFLOPS = {"float32": 157.3, "float64": 78.6}   # MI355X_MICROARCH.md: peak FP32 / FP64 vector
 ISSUE_CYCLES = {"float32": 2.0, "float64": 4.0}          # cycles per wave64 VALU instruction on a SIMD-32 (fp64: half rate)
@@ -418,6 +418,18 @@ def mode_records(torch, args, dev):
     fp["workload"] = ("spart_materialize.fast_prelude = 1 (Engine.run(lidf='newton')): exact root of the LIDF equation + 8-point hot-spot "
                       "panels instead of the reference's stopped iteration; all 2162 bands evaluated; 1M spectra, fp32")
     rec["fast_prelude"] = fp
+    # --- canopy.lidf handed in (spart_materialize.lidf_in; the reference's SAILH reads it from the object, sailh.py:51): the
+    # prelude skips its 12 fixed-point solves per sample.  Here every row gets the distribution its own (LIDFa, LIDFb) gives
+    # (spart_lidf_batch), so the columns must be the pruned run's, bit for bit.
+    li = get_engine(None, dev.index).lidf(Pd[16], Pd[17])
+    rl = run_config(torch, eng, Pd, "float32", 20, 3, prune=True, canopy_lidf=li)
+    gl = eng.run(Pd, "float32", prune=True, canopy_lidf=li)
+    rec["lidf_given"] = {"workload": "prune_unused_bands = 1 with canopy.lidf given as a (B, 13) input (k_prelude<false, true>), 1M spectra, "
+                                     f"{args.sensor}: the cost of the returned columns when the leaf-angle distribution is data, not (LIDFa, LIDFb)",
+                         "value": rl["value"], "unit": "spectra/s", "ms_per_step": rl["ms_per_step"], "stage_ms": rl["stage_ms"],
+                         "columns_bit_identical_to_derived_lidf": all(bool(torch.equal(pr[k], gl[k])) for k in ("R_TOC", "R_TOA", "L_TOA")),
+                         "extra_input_bytes_per_spectrum": 13 * 8}
+    del li, gl
     del full, pr, nw
     # --- LUT inversion: 1M-row LUT (this run's R_TOC columns) x 65 536 observations, float32
     lut = eng.run(Pd, "float32")["R_TOC"].clone()
