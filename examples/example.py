@@ -28,8 +28,10 @@ canopy = SPART.CanopyStructure(LAI=rng.uniform(0.1, 7, B), LIDFa=-0.35, LIDFb=-0
 res = SPART.SPART(soilpar, leafbio, canopy, atm, angles, sensor="Sentinel2A-MSI", DOY=100, dtype="float32").run()
 print(type(res).__name__, res["R_TOC"].shape, res["R_TOA"].mean(axis=0))
 
-# the model's tables are the object's public attributes, read on every run() like in the reference (SPART.py:93-95):
-# a 5 % stronger chlorophyll absorption and a Sentinel-2 band moved by 3.5 nm, no new object needed
+# the model's tables are the object's public attributes (SPART.py:93-95) and are read on EVERY run() here: a 5 % stronger
+# chlorophyll absorption and a Sentinel-2 band moved by 3.5 nm, no new object needed.  (Upstream reads them only while its change
+# trackers are set, SPART.py:178-209: after a first run() this very edit would return the first answer again until a setter
+# such as `sp.leafbio = sp.leafbio` flips a tracker -- this package is stateless by design, see SPART.run.__doc__.)
 sp = SPART.SPART(soilpar, SPART.LeafBiology(40, 0.01, 0.02, 0, 10, 10, 1.5), SPART.CanopyStructure(3, -0.35, -0.15, 0.05), atm, angles,
                  sensor="Sentinel2A-MSI", DOY=100)
 before = sp.run()
@@ -37,3 +39,11 @@ sp.optipar["Kab"] *= 1.05
 sp.sensorinfo["wl_smac"] = sp.sensorinfo["wl_smac"].astype(float) + 3.5
 after = sp.run()
 print("R_TOC at the red band: %.5f -> %.5f (centre %g -> %g nm)" % (before["R_TOC"].iloc[3], after["R_TOC"].iloc[3], before.index[3], after.index[3]))
+
+# the canopy state SAILH reads from the object (sailh.py:48, 51): a measured leaf-angle distribution instead of (LIDFa, LIDFb),
+# and another number of canopy layers
+canopy = SPART.CanopyStructure(LAI=3, LIDFa=-0.35, LIDFb=-0.15, q=0.05)
+canopy.lidf = np.array([0.22, 0.19, 0.16, 0.13, 0.10, 0.07, 0.05, 0.03, 0.02, 0.01, 0.01, 0.005, 0.005])[:, None]   # 13 classes, sums to 1
+canopy.nlayers = 30
+sp = SPART.SPART(soilpar, SPART.LeafBiology(40, 0.01, 0.02, 0, 10, 10, 1.5), canopy, atm, angles, sensor="Sentinel2A-MSI", DOY=100)
+print("planophile table, 30 layers: R_TOC(NIR) = %.5f (spherical-ish default: %.5f)" % (sp.run()["R_TOC"].iloc[8], before["R_TOC"].iloc[8]))

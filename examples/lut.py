@@ -29,3 +29,12 @@ idx, cost = eng.lut_nearest(torch.as_tensor(np.ascontiguousarray(cols["R_TOA"]),
 idx = idx.cpu().numpy()
 print("recovered the generating row for", float((idx == pick).mean()) * 100, "% of the spectra;",
       "median |LAI error| =", float(np.median(np.abs(params[idx, 15] - params[pick, 15]))))
+
+# the same on several GPUs (one process per GPU; nothing changes at one):
+#     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 examples/lut.py
+# with, in the script, torch.distributed.init_process_group("nccl") and
+#     generate_lut(P, "Sentinel2A-MSI", out, shard=True)        every rank writes its own rows of the same .npy files, no gather
+#     idx, cost = spart_amd.invert_lut(out, obs, column="R_TOA", shard=True)   per-rank search + ONE all_gather of the winners
+from spart_amd import invert_lut  # noqa: E402
+idx2, cost2 = invert_lut(out, obs, column="R_TOA")              # one process: the whole directory on this GPU
+assert np.array_equal(idx2, idx)
