@@ -1,10 +1,11 @@
 """Every measured number the documents quote, printed FROM THE COMMITTED FILES of one collection (VERDICT r4 "Weak 9":
 documents disagreed with the files they cited because numbers were typed by hand after re-collections).
 
-    python tools/profile_report.py r5_final r5            print the markdown block
-    python tools/profile_report.py r5_final r5 --write    ... and replace the text between the markers
+    python tools/profile_report.py r6_final r6            print the markdown block
+    python tools/profile_report.py r6_final r6 --write    ... and replace the text between the markers
                                                           <!-- profile_report:begin --> / <!-- profile_report:end -->
-                                                          in profiles/README.md and DESIGN.md with it
+                                                          in profiles/README.md with it (everything) and in DESIGN.md with
+                                                          its first table only (one short row per bench record)
 
 Reads profiles/<tag>_bench.json, <tag>_kernel_stats_*.csv, <tag>_<mode>_kernel_stats.csv, <prefix>_counters_*.json,
 <tag>_power_*.txt, <tag>_c2_bench.txt, <tag>_mode_cost.txt, <tag>_parity_*.json when they exist; a missing file is
@@ -55,55 +56,71 @@ def power(path):
     return f"{min(w):.0f}-{max(w):.0f} W, sclk {min(c)}-{max(c)} MHz ({len(w)} samples)" if c else f"{min(w):.0f}-{max(w):.0f} W"
 
 
-R4 = {"headline": "8.87e7, 11.27 ms, frac 0.552, 2.48 GB", "returned": "6.79e8, 1.47 ms, 2.16 GB", "fp64": "4.14e7", "c3": "7.97e7 / 8.39e7", "c2": "0.152 ms",
-      "c5": "8.80e7", "mat": "5.67e7", "lut": "4.51e12", "lutgen": "6.63e7"}      # round 4's line (profiles/r4_final_bench.json), for comparison
+def _line(path):
+    try:
+        return json.loads(open(path).read().strip().splitlines()[-1])
+    except Exception:      # noqa: BLE001
+        return None
 
 
-def summary_table(tag, d):
-    """the BASELINE-config table of DESIGN.md section 8, every figure from <tag>_bench.json"""
+def summary_table(tag, d, prev_tag=None):
+    """the BASELINE-config table of DESIGN.md section 8: one short row per record, every figure from <tag>_bench.json, the previous
+    round's value of the same field beside it (from <prev_tag>_bench.json)"""
+    p = _line(os.path.join(PROF, f"{prev_tag}_bench.json")) if prev_tag else None
     r, c, f = d["roofline"], d.get("configs") or {}, d.get("fp64") or {}
-    pr, cb = c.get("pruned", {}), d.get("cpu_baseline") or {}
-    g = lambda k: c.get(k, {})                                                    # noqa: E731
-    rows = ["| BASELINE config | value (round 5, `" + tag + "_bench.json`) | round 4 |", "|---|---|---|"]
-    rows.append(f"| 4 (headline): full SPART, B = 1M, Sentinel-2A, fp32, all 2162 bands, columns = float64 column path | **{d['value']:.3g} spectra/s** ({d['ms_per_step']:.2f} ms/step: "
-                f"`k_prelude` {r['stage_ms']['prelude']:.2f}, then `k_bands` {r['kernel_ms']:.2f} with `k_columns` beside it on the side stream); `roofline.frac` **{r['frac']:.3f}** "
-                f"(issue fraction {r.get('issue', {}).get('issue_frac', 0):.3f}); counter traffic {(r.get('traffic') or 0) / 1e9:.2f} GB per step = {r['hbm'].get('ratio_to_algorithmic', 0):.1f} x the algorithmic bytes; "
-                f"with `fast_prelude` {g('fast_prelude').get('value', 0):.3g} ({g('fast_prelude').get('ms_per_step', 0):.2f} ms) -- target was >= 1e6 | {R4['headline']} |")
-    pi = (pr.get("roofline") or {}).get("issue") or {}
-    iss = "; ".join(f"{k} {v['issue_frac']:.2f} of the 4-cycle float64 issue rate = {v['frac_of_measured_fma_f64_rate']:.2f} of the MEASURED v_fma_f64 rate" for k, v in pi.items())
-    rows.append(f"| `returned_columns` = `configs.pruned` (the SECOND headline: what the `R_TOC / R_TOA / L_TOA` a caller receives cost; `prune_unused_bands = 1`, NOT full spectra) | "
-                f"**{pr.get('value', 0):.3g} spectra/s** ({pr.get('ms_per_step', 0):.3f} ms per 1M: prelude {pr.get('stage_ms', {}).get('prelude', 0):.3f} + column kernel {pr.get('stage_ms', {}).get('columns', 0):.3f}), "
-                f"columns bit-identical to the full evaluation: {pr.get('columns_bit_identical_to_full_evaluation')}; counter traffic **{((pr.get('roofline') or {}).get('traffic') or 0) / 1e9:.2f} GB**; {iss}; "
-                f"with `fast_prelude` {(pr.get('with_fast_prelude') or {}).get('ms_per_step', 0):.3f} ms | {R4['returned']} |")
-    fr = f.get("roofline", {})
-    rows.append(f"| same as 4 in fp64 (`fp64` sub-record) | **{f.get('value', 0):.3g} spectra/s** ({f.get('ms_per_step', 0):.2f} ms; band kernel {fr.get('kernel_ms', 0):.2f} ms, `roofline.frac` {fr.get('frac', 0):.3f}); "
-                f"the same float64 columns over a float32 evaluation of the 2162 bands (`f32_bands`): the headline's rate, identical by construction | {R4['fp64']} |")
-    rows.append(f"| 3: B = 100k, Sentinel-2A, fp32 (`configs.3`, HIP-graph replays) | {g('3').get('value', 0):.3g} spectra/s ({g('3').get('ms_per_step', 0):.3f} ms); 125k (the per-GPU shard of config 4 cut in 8): "
-                f"{g('4_shard_125k').get('value', 0):.3g} ({g('4_shard_125k').get('ms_per_step', 0):.3f} ms) | {R4['c3']} |")
+    pc, pf = ((p or {}).get("configs") or {}), ((p or {}).get("fp64") or {})
+    g = lambda k, src=c: src.get(k, {}) or {}                                       # noqa: E731
+    rf = lambda x: (x.get("roofline") or {})                                        # noqa: E731
+
+    def v(x, k="value", fmt="{:.3g}"):
+        return fmt.format(x[k]) if isinstance(x, dict) and x.get(k) is not None else "--"
+    rows = [f"| record (`{tag}_bench.json`) | value | ms per step | `roofline.frac` (bound) | {prev_tag or 'previous'} value |", "|---|---|---|---|---|"]
+    rows.append(f"| **headline = config 4**: full SPART, 1M, S2A, fp32, all 2162 bands | **{d['value']:.3g} spectra/s** | {d['ms_per_step']:.2f} (`k_bands` {r['kernel_ms']:.2f}) | "
+                f"**{r['frac']:.3f}** ({r['bound']}; issue {r.get('issue', {}).get('issue_frac', 0):.2f}) | {v(p)} |")
+    pr = g("pruned")
+    rows.append(f"| `returned_columns` = `configs.pruned` (what the returned `R_TOC / R_TOA / L_TOA` cost) | **{v(pr)} spectra/s** | {v(pr, 'ms_per_step', '{:.3f}')} | "
+                "issue " + ", ".join("%s %.2f" % (k, x["issue_frac"]) for k, x in (rf(pr).get("issue") or {}).items()) + f"; traffic {(rf(pr).get('traffic') or 0) / 1e9:.2f} GB | {v(g('pruned', pc))} |")
+    lg = g("lidf_given")
+    if lg:
+        rows.append(f"| `configs.lidf_given`: the same with `canopy.lidf` as a (B,13) input | {v(lg)} spectra/s | {v(lg, 'ms_per_step', '{:.3f}')} (prelude {lg.get('stage_ms', {}).get('prelude', 0):.3f}) | "
+                    f"columns bit-identical: {lg.get('columns_bit_identical_to_derived_lidf')} | -- |")
+    rows.append(f"| `fp64`: config 4 in the reference's precision | {v(f)} spectra/s | {v(f, 'ms_per_step', '{:.2f}')} | {rf(f).get('frac', 0):.3f} (valu) | {v(pf)} |")
     c2 = g("2")
-    rows.append(f"| 2: PROSPECT-5D leaf only, 10k x 2001, fp64 (`configs.2`) | {c2.get('ms_per_step', 0):.3f} ms per call = {c2.get('value', 0):.3g} leaf spectra/s = {(c2.get('roofline') or {}).get('achieved', 0) / 1e3:.2f} TB/s "
-                f"of the 48 096 B/spectrum (`roofline.frac` {(c2.get('roofline') or {}).get('frac', 0):.3f}); package-power-bound (section 4) | {R4['c2']} |")
-    rows.append(f"| 5: PROSPECT-PRO + SAILH, B = 1M, Sentinel-2B (`configs.5`) | {g('5').get('value', 0):.3g} spectra/s fp32 ({g('5').get('ms_per_step', 0):.2f} ms); fp32 vs fp64 max "
-                f"{max((g('5').get('fp32_vs_fp64_max_rel_floor1e-6') or {'x': 0}).values()):.3g} on the three columns (floor 1e-6) | {R4['c5']} |")
+    mo = c2.get("max_abs_vs_oracle") or {}
+    rows.append(f"| `configs.2`: PROSPECT-5D only, 10k x 2001, fp64 | {v(c2)} leaf spectra/s | {v(c2, 'ms_per_step', '{:.4f}')} | {rf(c2).get('frac', 0):.3f} (hbm: {rf(c2).get('achieved', 0) / 1e3:.2f} TB/s); "
+                f"max abs vs oracle {max([x for k, x in mo.items() if k != 'rows'] or [float('nan')]):.1e} on {mo.get('rows', 0)} rows | {v(g('2', pc))} |")
+    rows.append(f"| `configs.3`: 100k, S2A, fp32 (HIP-graph replays); `4_shard_125k` | {v(g('3'))} ; {v(g('4_shard_125k'))} | {v(g('3'), 'ms_per_step', '{:.3f}')} ; {v(g('4_shard_125k'), 'ms_per_step', '{:.3f}')} | -- | {v(g('3', pc))} ; {v(g('4_shard_125k', pc))} |")
+    c5 = g("5")
+    rows.append(f"| `configs.5`: PROSPECT-PRO + SAILH, 1M, S2B, fp32 (fp64) | {v(c5)} ({v(c5, 'fp64_value')}) | {v(c5, 'ms_per_step', '{:.2f}')} | fp32 vs fp64 max "
+                f"{max((c5.get('fp32_vs_fp64_max_rel_floor1e-6') or {'x': 0}).values()):.2g} | {v(g('5', pc))} |")
     m = g("materialized")
-    rows.append(f"| `configs.materialized` (9 arrays, 75 KB/spectrum fp32, B = 200k, padded row pitch) | {m.get('value', 0):.3g} spectra/s ({m.get('ms_per_step', 0):.3f} ms/step; `roofline.frac` {(m.get('roofline') or {}).get('frac', 0):.3f} = "
-                f"{(m.get('roofline') or {}).get('achieved', 0) / 1e3:.2f} TB/s stored inside the band kernel); power-bound (power files below); follows the box: 5.4e7 ... 5.9e7 across the round's runs | {R4['mat']} |")
+    rows.append(f"| `configs.materialized`: 9 spectrum arrays, 200k, fp32 | {v(m)} spectra/s | {v(m, 'ms_per_step', '{:.3f}')} | {rf(m).get('frac', 0):.3f} (hbm: {rf(m).get('achieved', 0) / 1e3:.2f} TB/s stored) | {v(g('materialized', pc))} |")
     li = g("lut_invert")
-    rows.append(f"| `configs.lut_invert` (1M-row LUT x 65 536 observations, fp32) | {li.get('value', 0):.3g} row comparisons/s ({li.get('ms_per_step', 0):.2f} ms), {li.get('winners_equal_to_brute_force')} / {li.get('checked', 65536)} winners and "
-                f"{li.get('costs_bit_equal')} costs bit-equal to the brute force, `roofline.frac` {(li.get('roofline') or {}).get('frac', 0):.3f} of the MFMA peak, {li.get('observations_on_the_brute_force_path')} observations on the brute-force path | {R4['lut']} |")
-    rows.append(f"| `configs.lut_generate` (host table in, host columns out, 8M spectra) | {g('lut_generate').get('value', 0):.3g} spectra/s with all bands evaluated ({g('lut_generate').get('ms_per_step', 0):.0f} ms) | {R4['lutgen']} |")
+    rows.append(f"| `configs.lut_invert`: 1M-row LUT x 65 536 observations, fp32 | {v(li)} row comparisons/s | {v(li, 'ms_per_step', '{:.2f}')} | {rf(li).get('frac', 0):.3f} (mfma); "
+                f"{li.get('winners_equal_to_brute_force')} / {li.get('checked')} winners = brute force | {v(g('lut_invert', pc))} |")
+    lgn = g("lut_generate")
+    rows.append(f"| `configs.lut_generate`: 8M spectra, host table in, host columns out | {v(lgn)} spectra/s (pruned {v(lgn, 'pruned_value')}) | {v(lgn, 'ms_per_step', '{:.0f}')} | PCIe-inclusive | {v(g('lut_generate', pc))} |")
+    cb = d.get("cpu_baseline") or {}
     rr, ric = cb.get("reference_route", {}), cb.get("reference_in_container", {})
-    rows.append(f"| CPU, three figures side by side (`cpu_baseline`) | the reference itself, build container: {ric.get('value')} {ric.get('unit')} (`reference_in_container`, a stated constant: the reference cannot travel); "
-                f"the oracle on the reference's own QUADPACK route, ONE ROW PER CALL, GPU-box host: {rr.get('per_core', 0):.2g} per core, {rr.get('value', 0):.3g} on {rr.get('cores')} cores (`reference_route`); "
-                f"the vectorised port (closed forms, 256-row blocks): {cb.get('per_core', 0):.3g} per core, {cb.get('value', 0):.3g} on {cb.get('cores')} cores (`value`) | -- |")
+    rows.append(f"| `cpu_baseline` (kind {cb.get('kind')}, {cb.get('cores')} cores) | {v(cb)} spectra/s ({v(cb, 'per_core')} per core) | -- | reference route {v(rr, 'per_core', '{:.2g}')} / core; "
+                f"the reference itself {ric.get('value')} {ric.get('unit')} (build container) | -- |")
     return rows
 
 
-def block(tag, prefix):
+def design_block(tag, prefix, prev_tag):
+    """the compact block of DESIGN.md section 8"""
+    L = [f"_Generated by `python tools/profile_report.py {tag} {prefix} --write` from `profiles/{tag}_bench.json` (previous round: `{prev_tag}_bench.json`); "
+         "the per-file figures (kernel stats, counters, power) are in the generated block of `profiles/README.md`._", ""]
+    d = _line(os.path.join(PROF, f"{tag}_bench.json"))
+    L += summary_table(tag, d, prev_tag) if d else [f"* `{tag}_bench.json`: MISSING"]
+    return "\n".join(L) + "\n"
+
+
+def block(tag, prefix, prev_tag=None):
     L = [f"_Generated by `python tools/profile_report.py {tag} {prefix}` from the files named; do not edit by hand._", ""]
     bp0 = os.path.join(PROF, f"{tag}_bench.json")
     if os.path.exists(bp0):
-        L += summary_table(tag, json.loads(open(bp0).read().strip().splitlines()[-1])) + [""]
+        L += summary_table(tag, json.loads(open(bp0).read().strip().splitlines()[-1]), prev_tag) + [""]
     bp = os.path.join(PROF, f"{tag}_bench.json")
     if os.path.exists(bp):
         d = json.loads(open(bp).read().strip().splitlines()[-1])
@@ -201,10 +218,15 @@ def block(tag, prefix):
 
 def main():
     tag, prefix = sys.argv[1], sys.argv[2] if len(sys.argv) > 2 and not sys.argv[2].startswith("--") else sys.argv[1].split("_")[0]
-    text = block(tag, prefix)
+    prev = next((a.split("=", 1)[1] for a in sys.argv if a.startswith("--prev=")), None)
+    if prev is None:                                   # the previous round's collection, if its line is committed
+        n = re.match(r"r(\d+)_", tag)
+        cand = f"r{int(n.group(1)) - 1}_final" if n else None
+        prev = cand if cand and os.path.exists(os.path.join(PROF, f"{cand}_bench.json")) else None
+    text = block(tag, prefix, prev)
     print(text)
     if "--write" in sys.argv:
-        for doc in (os.path.join(PROF, "README.md"), os.path.join(ROOT, "DESIGN.md")):
+        for doc, text in ((os.path.join(PROF, "README.md"), text), (os.path.join(ROOT, "DESIGN.md"), design_block(tag, prefix, prev))):
             s = open(doc).read()
             if BEGIN not in s or END not in s:
                 print(f"[profile_report] {doc}: markers not found, left alone", file=sys.stderr)
