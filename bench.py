@@ -732,8 +732,11 @@ def main():
     if world > 1 and not args.no_extras and args.dtype == "float32":
         rows = diag["rows_per_rank"]
         gathered = torch.cat([g[0, :n] for g, n in zip(gather_lists[0], rows)]) if rank == 0 else None
-        lut_rec = lut_records_multi_rank(torch, dist, args, dev, eng, rank, world, res[0][0, :B].clone(), lo if scaling == "strong" else sum(rows[:rank]),
-                                         rows, gathered)
+        try:
+            lut_rec = lut_records_multi_rank(torch, dist, args, dev, eng, rank, world, res[0][0, :B].clone(),
+                                             lo if scaling == "strong" else sum(rows[:rank]), rows, gathered)
+        except Exception as e:      # noqa: BLE001  (never lose the headline line to a side record; the error is IN the line)
+            lut_rec = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         ok = all(bool(torch.isfinite(r).all().item()) for r in res)
         if world > 1:
