@@ -544,9 +544,12 @@ def lut_records_multi_rank(torch, dist, args, dev, eng, rank, world, lut_local, 
     dist.all_gather_object(owns, own * 1e3)
     chk = None
     if rank == 0:
-        si, sc = eng0.lut_nearest(gathered_lut, obs)
-        chk = {"winners_equal_to_single_device_search": int((idx.to(dev) == si).sum().item()),
-               "costs_bit_equal": int((cost.to(dev) == sc).sum().item()), "checked": M}
+        try:            # rank-0-only work: must never make rank 0 leave the collective sequence the other ranks follow
+            si, sc = eng0.lut_nearest(gathered_lut, obs)
+            chk = {"winners_equal_to_single_device_search": int((idx.to(dev) == si).sum().item()),
+                   "costs_bit_equal": int((cost.to(dev) == sc).sum().item()), "checked": M}
+        except Exception as e:      # noqa: BLE001
+            chk = {"check_error": f"{type(e).__name__}: {e}"}
     rec["lut_invert"] = dict({
         "workload": f"spart_amd.sharding.lut_nearest_sharded: {Bg}-row LUT (R_TOC of the global table) ROW-SHARDED over {world} ranks x "
                     f"{M} replicated observations, fp32: per-rank exact search + ONE all_gather of (cost, global row) -- 16 B x M per rank",

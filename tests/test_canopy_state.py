@@ -253,3 +253,40 @@ def test_second_run_is_stateless_where_the_reference_is_stale(fx):
         assert first.equals(keep)                        # an earlier result is not touched by a later run (staging is reused)
         assert list(second.columns) == ["Band", "L_TOA", "R_TOA", "R_TOC"] and list(second.index)[:2] == [445, 520]
         assert second["Band"].dtype == object and second["R_TOC"].dtype == np.float64
+
+
+@pytest.mark.gpu
+def test_canopy_state_at_size_and_in_every_prelude_variant(oracle, tables):
+    """B = 100 003 (391 prelude workgroups, a ragged last one) with a per-row lidf and nlayers = 24: 48 probe rows (front,
+    workgroup boundaries, tail, random) are bit-identical to the same rows evaluated as one-sample batches and agree with the
+    oracle; the Newton / 8-point prelude (`lidf="newton"`, `f32_columns`) takes the given distribution too."""
+    import torch
+    from spart_amd import get_engine, workloads
+    eng = get_engine("Sentinel2A-MSI", 0)
+    B = 100_003
+    P = workloads.lhs_params(B, "full", seed=41)
+    rng = np.random.default_rng(8)
+    lidf = rng.dirichlet(np.full(13, 2.0), size=B)                   # every row its own distribution (sums to 1)
+    Pd = torch.as_tensor(P.T.copy(), device="cuda:0")
+    li = torch.as_tensor(lidf, device="cuda:0")
+    probe = np.unique(np.concatenate([[0, 1, 63, 64, 255, 256, 257, 511, 512, B - 260, B - 257, B - 256, B - 2, B - 1],
+                                      rng.integers(0, B, 34)]))
+    with np.errstate(all="ignore"):
+        o = oracle.spart_run(P[probe], "Sentinel2A-MSI", tables, pso="gl", lidf=lidf[probe], nlayers=24)
+    for dtype, kw, tol in (("float64", {}, 1e-8), ("float32", {}, 1e-4), ("float64", {"lidf": "newton"}, 1e-6),
+                           ("float32", {"f32_columns": True}, 1e-4)):
+        full = eng.run(Pd, dtype, prune=True, canopy_lidf=li, nlayers=24, **kw)
+        for k in ("R_TOC", "R_TOA", "L_TOA"):
+            got = full[k][torch.as_tensor(probe, device="cuda:0")]
+            assert rel_err(got.double().cpu().numpy(), o[k], 1e-6) < tol, (dtype, kw, k)
+        if not kw:
+            for j in probe[::4]:
+                one = eng.run(Pd[:, j:j + 1].contiguous(), dtype, prune=True, canopy_lidf=li[j:j + 1], nlayers=24)
+                assert all(torch.equal(one[k][0], full[k][j]) for k in ("R_TOC", "R_TOA", "L_TOA")), (dtype, int(j))
+    # nlayers alone at size (the sorted default prelude with a user layer count), and a very large layer count: Pso[nl] -> Pso(-1)
+    a = eng.run(Pd, "float64", prune=True, nlayers=1_000_000)
+    b = eng.run(Pd, "float64", prune=True, nlayers=100_000)
+    assert torch.isfinite(a["R_TOC"]).all() and float((a["R_TOC"] - b["R_TOC"]).abs().max()) < 1e-5
+    # empty batch with a given lidf: nothing to do, no error
+    e = eng.run(Pd[:, :0].contiguous(), "float64", canopy_lidf=li[:0], nlayers=24)
+    assert e["R_TOC"].shape == (0, 13)
