@@ -410,6 +410,10 @@ class SpectralBands:
         self.IwlT = np.arange(self.nwlP, self.nwlP + self.nwlT, 1)
 
 
+_WLS_DEFAULT = np.concatenate([np.arange(400, 2401, 1), np.arange(2500, 15001, 100), np.arange(16000, 50001, 1000)])
+_WLS_DEFAULT.setflags(write=False)
+
+
 def set_soil_refl_trans_assumptions(soilopt, spectral):
     """SPART.py:427-442: pad the soil spectrum with its 2400 nm value (mutates and returns soilopt)."""
     r = np.asarray(soilopt.refl)
@@ -581,6 +585,11 @@ class SPART:
         both edits take effect on the next run()."""
         import pandas as pd
         _pro_warning(self.leafbio)
+        # the wavelength axis run() interpolates over (SPART.py:220-223 reads self.spectral.wlS): the kernels are built for the
+        # reference's grid, so an edited axis is refused, not ignored
+        wls = getattr(self.spectral, "wlS", None)
+        if not (np.shape(wls) == _WLS_DEFAULT.shape and np.array_equal(wls, _WLS_DEFAULT)):
+            raise ValueError("SPART.spectral.wlS differs from the reference's 2162-point grid (SPART.py:303-310): not supported")
         eng, wl, bands, wl_index, bands_arr = self._engine()
         cols = self._columns()
         rdry = self.soilpar.rdry if getattr(self.soilpar, "rdry_set", False) else None

@@ -247,3 +247,48 @@ def test_lut_brute_force_checkers_agree():
                     i2, c2 = brute_force_torch(torch.tensor(lut), torch.tensor(obs), None if w is None else torch.tensor(w), max_elems=block)
                     assert np.array_equal(i1, i2.numpy()) and np.array_equal(c1, c2.numpy()), (dt, nb, block)
                 assert i1[0] == 7 and i1[1] == 7 and i1[5] == -1 and np.isinf(c1[5]) and c1[0] == 0
+
+
+def test_raw_digest_sees_every_edit_of_the_table_dicts():
+    """engine.raw_digest (the key of SPART.run's per-object engine memo): equal for equal content in different dict / array
+    objects, different after a replaced array, an in-place edit, a changed dtype, a changed band id, a missing key."""
+    from spart_amd import engine as E, tables as T
+    op, et, si = T.load_optical_parameters(), T.load_ET_parameters(), T.load_sensor_info("Sentinel2A-MSI")
+    d0 = E.raw_digest(op, et, si)
+    assert E.raw_digest(T.load_optical_parameters(), T.load_ET_parameters(), T.load_sensor_info("Sentinel2A-MSI")) == d0
+    assert E.raw_digest(op, et, T.load_sensor_info("Sentinel2B-MSI")) != d0
+    seen = {d0}
+
+    def fresh(d):
+        assert d not in seen
+        seen.add(d)
+    op["Kw"] *= 1.0000001                                               # in place
+    fresh(E.raw_digest(op, et, si))
+    op["Kab"] = np.asarray(op["Kab"]) * 1.1                             # replaced
+    fresh(E.raw_digest(op, et, si))
+    t = np.asarray(si["SMAC_coef"]["taur"])
+    si["SMAC_coef"]["taur"] = t.astype(np.float32 if t.dtype == np.float64 else np.float64)   # (nearly) the same values, another dtype
+    fresh(E.raw_digest(op, et, si))
+    si["band_id_smac"] = ["x" + str(b) for b in si["band_id_smac"]]
+    fresh(E.raw_digest(op, et, si))
+    et["Ea"] = np.ascontiguousarray(np.asarray(et["Ea"])[::-1])          # a non-contiguous source made contiguous: content differs
+    fresh(E.raw_digest(op, et, si))
+    del op["GSV"]
+    fresh(E.raw_digest(op, et, si))
+    fresh(E.raw_digest(None, None, None))
+
+
+def test_an_edited_spectral_axis_is_refused_not_ignored():
+    """SPART.run() interpolates over self.spectral.wlS (SPART.py:220-223): the kernels are built for the reference's grid, so an
+    object whose axis was edited raises before any device work (no GPU needed to see it)."""
+    import warnings
+    from spart_amd import api
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        sp = api.SPART.__new__(api.SPART)
+    sp.leafbio = api.LeafBiology(40, 0.01, 0.02, 0, 10, 10, 1.5)
+    sp.spectral = api.SpectralBands()
+    assert sp.spectral.wlS.shape == (2162,) and sp.spectral.nwlP == 2001 and sp.spectral.nwlT == 161
+    sp.spectral.wlS = sp.spectral.wlS + 1
+    with pytest.raises(ValueError, match="wlS"):
+        sp.run()
