@@ -207,7 +207,9 @@ class SoilParametersFromFile:
 
 def soilwat(rdry, nw, kw, SMp, SMC, deleff, dtype="float64", device=None):
     """bsm.py:62-128: wet soil reflectance from a dry spectrum with the water tables ``nw`` / ``kw`` GIVEN (None = the
-    packaged ones): a device context holding exactly those two tables evaluates it.  Returns the shape of ``rdry``."""
+    packaged ones): a device context holding exactly those two tables evaluates it.  Returns what the reference's function
+    returns -- ``SoilOptics(rwet, rdry)`` (bsm.py:126-128; its docstring says "np.array", its code returns the object):
+    ``refl`` has the shape of ``rdry``, ``refl_dry`` IS the ``rdry`` handed in."""
     op = {}
     if nw is not None:
         op["nw"] = nw
@@ -215,7 +217,8 @@ def soilwat(rdry, nw, kw, SMp, SMC, deleff, dtype="float64", device=None):
         op["Kw"] = kw
     eng = _engine.get_engine(None, device, optical_params=op or None, need=tuple(op))
     refl, _ = eng.bsm([None, None, None, SMp, SMC, deleff], dtype, rdry=rdry)
-    return refl.cpu().numpy().reshape(np.shape(rdry)) if np.size(rdry) == 2001 else refl.cpu().numpy()
+    wet = refl.cpu().numpy().reshape(np.shape(rdry)) if np.size(rdry) == 2001 else refl.cpu().numpy()
+    return SoilOptics(wet, rdry)
 
 
 def BSM(soilpar, optical_params=None, dtype="float64", device=None):
@@ -623,7 +626,8 @@ class SPART:
             out = {k: (host[ncol.index(k)] if k in ncol else _np(v)) for k, v in res.items()}
             scalar = _is_scalar(*[c for c in cols if c is not None]) and out["R_TOC"].shape[0] == 1
         # attributes documented at SPART.py:66-81
-        self.R_TOC, self.R_TOA, self.L_TOA, self._La = out["R_TOC"], out["R_TOA"], out["L_TOA"], out["La"]
+        self.R_TOC, self.R_TOA, self.L_TOA = out["R_TOC"], out["R_TOA"], out["L_TOA"]       # (1, nb) for scalars, as upstream (SPART.py:250-252)
+        self._La = out["La"][0] if scalar else out["La"]                                   # (nb,) for scalars (SPART.py:183)
         # what the lazy attributes are evaluated from: COPIES of the parameters and the dtype of THIS run (the reference sets the
         # attributes eagerly in run(): mutating an input array in place or changing sp.dtype afterwards must not change them)
         snap = lambda c: None if c is None else (np.array(c, copy=True) if isinstance(c, np.ndarray) else (c.clone() if hasattr(c, "clone") else c))  # noqa: E731

@@ -38,6 +38,8 @@ Files
                  (python tests/golden/make_golden.py canopy_state)
   config2.npz    BASELINE config 2's own workload: the first 32 rows of workloads.lhs_params(10_000, "leaf") (7-D LHS, PROT = CBC = 0)
                  through PROSPECT_5D: leaf (32,9) + refl / tran / kChlrel (32,2001)   (prospect_5d.py:117-246)
+  surface.json   the SHAPE of the reference's public surface (surface_probe.py: return types, attribute names, array shapes and dtypes of
+                 every public callable on the hot path, S2A + MODIS), for the drop-in audit of tests/test_surface.py
   edge.npz       128 rows of tools/edge_sweep.py's widened ranges with edge values (LAI 0 / 1e-4 / 10, dry soil, N = 1,
                  zero pigments, exact hot spot, grazing angles, PRO leaves), Sentinel2A: P + R_TOC / R_TOA / L_TOA
 """
@@ -521,6 +523,15 @@ def _stale_rows(sensor):
         print("stale", tag, "second == first:", bool(np.array_equal(second["R_TOC"].to_numpy(), first["R_TOC"].to_numpy())),
               "fresh moved by %.2e" % np.max(np.abs(fr["R_TOC"].to_numpy() / first["R_TOC"].to_numpy() - 1)), flush=True)
     return out
+
+
+def gen_surface():
+    import json
+    import surface_probe
+    out = surface_probe.probe(SPART)
+    with open(os.path.join(HERE, "surface.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("surface", len(json.dumps(out)), "bytes")
 
 
 def gen_canopy_state():

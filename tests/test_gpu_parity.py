@@ -563,14 +563,16 @@ def test_soilwat_entry_point(oracle, tables, golden):
     op = SPART.load_optical_parameters()
     rdry = golden["rdry"]["spectra"][0][:, None]
     for smp in (30.0, 4.0):
-        a = soilwat(rdry, op["nw"], op["Kw"], smp, 25, 0.015)
+        so = soilwat(rdry, op["nw"], op["Kw"], smp, 25, 0.015)
+        assert isinstance(so, SPART.bsm.SoilOptics) and so.refl_dry is rdry                 # SoilOptics(rwet, rdry), bsm.py:126-128
+        a = so.refl
         b, _ = oracle.bsm(np.array([[0.5, 0, 100, smp, 25, 0.015]]), tables, rdry=rdry[:, 0][None, :])
         assert a.shape == (2001, 1) and rel_err(a[:, 0], b[0], 1e-6) < 1e-9, smp
-    assert np.array_equal(soilwat(rdry, op["nw"], op["Kw"], 4.0, 25, 0.015), rdry)         # bsm.py:101-103
+    assert np.array_equal(soilwat(rdry, op["nw"], op["Kw"], 4.0, 25, 0.015).refl, rdry)    # bsm.py:101-103
     # a foreign water table is HONOURED (round 5; it was refused before): the oracle with the same table agrees
     t2 = dict(tables)
     t2["nw"] = tables["nw"] * 1.01
-    a = soilwat(rdry, op["nw"] * 1.01, op["Kw"], 30.0, 25, 0.015)
+    a = soilwat(rdry, op["nw"] * 1.01, op["Kw"], 30.0, 25, 0.015).refl
     b, _ = oracle.bsm(np.array([[0.5, 0, 100, 30.0, 25, 0.015]]), t2, rdry=rdry[:, 0][None, :])
     b0, _ = oracle.bsm(np.array([[0.5, 0, 100, 30.0, 25, 0.015]]), tables, rdry=rdry[:, 0][None, :])
     assert rel_err(a[:, 0], b[0], 1e-6) < 1e-9 and rel_err(a[:, 0], b0[0], 1e-6) > 1e-4
