@@ -107,6 +107,42 @@ def test_two_gloo_ranks_with_the_hip_evaluator_match_single_rank():
     assert same                                                    # shards are independent: bit-identical to one rank
 
 
+def test_eight_simulated_shards_on_one_gpu():
+    """the 8-way split of BASELINE config 4 rehearsed on ONE device, no process group: the eight contiguous shards of
+    sharding.shard_bounds evaluated one after the other and concatenated are bit-identical to the single evaluation (ragged last
+    shard), and the LUT inversion over eight row blocks -- the per-block winners stacked as the all_gather would stack them, then
+    sharding.select_nearest -- returns the single search's winners and costs."""
+    import torch
+    from spart_amd import get_engine, sharding, workloads
+    eng = get_engine("Sentinel2A-MSI", 0)
+    B, G = 200_003, 8
+    P = torch.as_tensor(workloads.lhs_params(B, "full", seed=5).T.copy(), device="cuda:0")
+    whole = {k: v.clone() for k, v in eng.run(P, "float32").items()}
+    parts = {k: [] for k in whole}
+    rows = 0
+    for r in range(G):
+        lo, hi = sharding.shard_bounds(B, G, r)
+        o = eng.run(P[:, lo:hi].contiguous(), "float32")
+        for k in parts:
+            parts[k].append(o[k].clone())
+        rows += hi - lo
+    assert rows == B and sharding.shard_bounds(B, G, 7) == (175_007, 200_003)
+    for k in whole:
+        assert torch.equal(torch.cat(parts[k]), whole[k]), k
+    lut = whole["R_TOC"]
+    g = torch.Generator(device="cuda:0").manual_seed(2)
+    obs = lut[torch.randint(0, B, (4096,), generator=g, device="cuda:0")] * (1 + 0.02 * torch.randn((4096, 13), generator=g, device="cuda:0"))
+    si, sc = eng.lut_nearest(lut, obs)
+    costs, idxs = [], []
+    for r in range(G):
+        lo, hi = sharding.shard_bounds(B, G, r)
+        i, c = sharding.lut_nearest_sharded(lut[lo:hi], lo, obs, eng.lut_nearest)      # (no group: the local search with global rows)
+        costs.append(c)
+        idxs.append(i)
+    bi, bc = sharding.select_nearest(torch.stack(costs), torch.stack(idxs))
+    assert torch.equal(bi, si) and torch.equal(bc, sc)
+
+
 def _lut_rank(rank, world, port, path, B, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, os.path.join(ROOT, "spart-python_amd"))
