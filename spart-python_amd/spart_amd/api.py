@@ -6,7 +6,7 @@ calls return objects shaped like the reference's ((n,1) column vectors, a pandas
 from SPART.run()); batched calls return (B, n) arrays.
 """
 import warnings
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 
 import numpy as np
 

@@ -10,7 +10,6 @@ The LUT rows of SURVEY.md §8(f) shard the same way (contiguous blocks of ``ceil
 * inversion (lut_nearest_sharded below): every rank finds the exact nearest row of ITS block for every observation, then
   ONE all_gather of (cost, global row index) per observation -- 16 bytes x M per rank -- and the same selection rule on
   every rank: lowest cost, lowest row index on ties (the reference's np.argmin rule, SPART.py:381-387)."""
-import numpy as np
 
 
 def shard_bounds(B, world, rank):
