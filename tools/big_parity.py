@@ -1,6 +1,6 @@
 """Parity at scale on the GPU box: HIP fp64 / fp32 sensor columns against the oracle (16 host processes) on
-262 144 LHS rows of config 4 (Sentinel-2A) and config 5 (PROSPECT-PRO, Sentinel-2B) -- 128x the rows the test suite
-compares.  Test infrastructure (imports oracle/); prints one JSON object."""
+262 144 LHS rows of config 4 (Sentinel-2A), config 5 (PROSPECT-PRO, Sentinel-2B) and -- round 6 -- config 4's rows with a per-row
+canopy.lidf and canopy.nlayers = 24 (the canopy state SAILH reads from the object, sailh.py:48, 51).  Test infrastructure (imports oracle/); prints one JSON object."""
 import json, multiprocessing as mp, os, sys, time
 ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 sys.path.insert(0, os.path.join(ROOT, "spart-python_amd"))
@@ -8,7 +8,15 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 
 ROWS = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
-CASES = (("full", "Sentinel2A-MSI"), ("pro", "Sentinel2B-MSI"))
+CASES = (("full", "Sentinel2A-MSI"), ("pro", "Sentinel2B-MSI"), ("canopy_state", "Sentinel2A-MSI"))
+NLAYERS = 24          # the "canopy_state" case: config 4's rows with a per-row canopy.lidf (Dirichlet draws) and canopy.nlayers = 24
+
+
+def case_inputs(kind):
+    """(lhs kind, per-row lidf or None, nlayers or None): what both sides evaluate"""
+    if kind != "canopy_state":
+        return kind, None, None
+    return "full", np.random.default_rng(778).dirichlet(np.full(13, 2.0), size=ROWS), NLAYERS
 
 
 def worker(job):
@@ -16,10 +24,12 @@ def worker(job):
     import spart_oracle as O
     from spart_amd import workloads
     T = O.load_tables()
-    P = workloads.lhs_params(ROWS, kind, seed=777)[lo:hi]
+    lk, lidf, nl = case_inputs(kind)
+    P = workloads.lhs_params(ROWS, lk, seed=777)[lo:hi]
     out = {k: [] for k in ("R_TOC", "R_TOA", "L_TOA")}
     for i in range(0, len(P), 256):
-        r = O.spart_run(P[i:i + 256], sensor, T, pso="gl")
+        kw = {} if lidf is None else dict(lidf=lidf[lo + i:lo + i + 256], nlayers=nl)
+        r = O.spart_run(P[i:i + 256], sensor, T, pso="gl", **kw)
         for k in out:
             out[k].append(r[k])
     return {k: np.concatenate(v) for k, v in out.items()}
@@ -38,10 +48,12 @@ def main():
     from spart_amd import get_engine, workloads
     res = {"rows": ROWS, "seed": 777}
     for kind, sensor in CASES:
-        P = torch.as_tensor(workloads.lhs_params(ROWS, kind, seed=777).T.copy(), device="cuda:0")
+        lk, lidf, nl = case_inputs(kind)
+        P = torch.as_tensor(workloads.lhs_params(ROWS, lk, seed=777).T.copy(), device="cuda:0")
         eng = get_engine(sensor, 0)
+        kw = {} if lidf is None else dict(canopy_lidf=torch.as_tensor(lidf, device="cuda:0"), nlayers=nl)
         for dtype in ("float64", "float32"):
-            o = eng.run(P, dtype)
+            o = eng.run(P, dtype, **kw)
             for k in ("R_TOC", "R_TOA", "L_TOA"):
                 x, r = o[k].double().cpu().numpy(), ref[kind][k]
                 d = np.abs(x - r)
