@@ -475,7 +475,7 @@ def mode_records(torch, args, dev):
     # --- LUT generation end to end: host parameter table in, host columns out (PCIe-inclusive; never the headline)
     P8 = np.tile(P1m, (8, 1))
     spart_amd.generate_lut(P8[:1 << 20], args.sensor, prune=False)
-    best, bestp = 1e9, 1e9
+    best, bestp, bestr = 1e9, 1e9, 1e9
     for _ in range(3):
         t0 = time.perf_counter()
         o = spart_amd.generate_lut(P8, args.sensor, prune=False)
@@ -484,6 +484,9 @@ def mode_records(torch, args, dev):
         t0 = time.perf_counter()
         o = spart_amd.generate_lut(P8, args.sensor, prune=True)
         bestp = min(bestp, time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        spart_amd.generate_lut(P8, args.sensor, prune=True, out=dict(o))      # destination pages resident (a reused result)
+        bestr = min(bestr, time.perf_counter() - t0)
         del o
     rec["lut_generate"] = {
         "workload": f"spart_amd.generate_lut: {P8.shape[0]} spectra (the 1M config-4 table x 8), {args.sensor}, fp32, pageable host table in -> "
@@ -492,6 +495,7 @@ def mode_records(torch, args, dev):
         "value": P8.shape[0] / best, "unit": "spectra/s", "ms_per_step": best * 1e3,
         "host_bytes_per_spectrum": 27 * 8 + 3 * eng.nb * 4, "host_GBps": (27 * 8 + 3 * eng.nb * 4) * P8.shape[0] / best / 1e9,
         "pruned_value": P8.shape[0] / bestp, "pruned_ms": bestp * 1e3,
+        "pruned_reused_destination_value": P8.shape[0] / bestr, "pruned_reused_destination_ms": bestr * 1e3,
         "note": "PCIe-inclusive, reported beside the resident-input headline (never as `value` of the line)"}
     return rec
 

@@ -786,6 +786,14 @@ def test_lut_generation_streams_chunks(tmp_path, torch_mod):
     mem = spart_amd.generate_lut(P[:100], "Sentinel2A-MSI", dtype="float64", chunk=64)
     ref64 = eng.run(torch_mod.as_tensor(P[:100].T.copy(), device="cuda:0"), "float64")
     assert np.array_equal(mem["R_TOC"], ref64["R_TOC"].cpu().numpy())
+    # a caller-owned destination (a previous result reused: its pages are resident) is filled in place; a wrong one is refused
+    mine = {k: np.full((B, 13), -1.0, dtype=np.float32) for k in ("R_TOC", "R_TOA", "L_TOA")}
+    again = spart_amd.generate_lut(P, "Sentinel2A-MSI", chunk=4096, out=mine)
+    assert all(again[k] is mine[k] and np.array_equal(mine[k], ref[k]) for k in mine) and again.rows == (0, B)
+    with pytest.raises(ValueError, match="R_TOA"):
+        spart_amd.generate_lut(P, "Sentinel2A-MSI", out=dict(mine, R_TOA=mine["R_TOA"][:-1]))
+    with pytest.raises(ValueError, match="R_TOC"):
+        spart_amd.generate_lut(P, "Sentinel2A-MSI", dtype="float64", out=mine)
     # (the parquet export of such a directory is covered without a GPU: tests/test_host_logic.py::test_lut_parquet_export,
     #  and -- where the box has a parquet engine -- end to end in test_lut_on_disk_parquet_leg below)
 
