@@ -99,7 +99,7 @@ def summary_table(tag, d, prev_tag=None):
     rows.append(f"| `configs.lut_invert`: 1M-row LUT x 65 536 observations, fp32 | {v(li)} row comparisons/s | {v(li, 'ms_per_step', '{:.2f}')} | {rf(li).get('frac', 0):.3f} (mfma); "
                 f"{li.get('winners_equal_to_brute_force')} / {li.get('checked')} winners = brute force | {v(g('lut_invert', pc))} |")
     lgn = g("lut_generate")
-    rows.append(f"| `configs.lut_generate`: 8M spectra, host table in, host columns out | {v(lgn)} spectra/s (pruned {v(lgn, 'pruned_value')}) | {v(lgn, 'ms_per_step', '{:.0f}')} | PCIe-inclusive | {v(g('lut_generate', pc))} |")
+    rows.append(f"| `configs.lut_generate`: 8M spectra, host table in, host columns out | {v(lgn)} spectra/s (pruned {v(lgn, 'pruned_value')}; into a reused destination {v(lgn, 'pruned_reused_destination_value')}) | {v(lgn, 'ms_per_step', '{:.0f}')} | PCIe-inclusive | {v(g('lut_generate', pc))} |")
     cb = d.get("cpu_baseline") or {}
     rr, ric = cb.get("reference_route", {}), cb.get("reference_in_container", {})
     rows.append(f"| `cpu_baseline` (kind {cb.get('kind')}, {cb.get('cores')} cores) | {v(cb)} spectra/s ({v(cb, 'per_core')} per core) | -- | reference route {v(rr, 'per_core', '{:.2g}')} / core; "
