@@ -292,3 +292,26 @@ def test_an_edited_spectral_axis_is_refused_not_ignored():
     sp.spectral.wlS = sp.spectral.wlS + 1
     with pytest.raises(ValueError, match="wlS"):
         sp.run()
+
+
+def test_generated_document_blocks_are_what_the_files_say():
+    """The measurement tables of DESIGN.md section 8 and profiles/README.md are printed from profiles/<tag>_* by tools/profile_report.py;
+    regenerating them from the committed files must reproduce the committed text (a number typed by hand, or a refreshed
+    profile without a refreshed document, fails here)."""
+    import importlib.util
+    import os
+    import re
+    root = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    spec = importlib.util.spec_from_file_location("profile_report", os.path.join(root, "tools", "profile_report.py"))
+    pr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pr)
+    design = open(os.path.join(root, "DESIGN.md")).read()
+    m = re.search(r"python tools/profile_report.py (\S+) (\S+) --write", design[design.index(pr.BEGIN):])
+    tag, prefix = m.group(1), m.group(2)
+    n = re.match(r"r(\d+)_", tag)
+    prev = f"r{int(n.group(1)) - 1}_final"
+    for doc, want in ((os.path.join(root, "DESIGN.md"), pr.design_block(tag, prefix, prev)),
+                      (os.path.join(root, "profiles", "README.md"), pr.block(tag, prefix, prev))):
+        s = open(doc).read()
+        got = s[s.index(pr.BEGIN) + len(pr.BEGIN):s.index(pr.END)]
+        assert got.strip() == want.strip(), f"{doc}: run `python tools/profile_report.py {tag} {prefix} --write`"
