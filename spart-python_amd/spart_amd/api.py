@@ -526,7 +526,11 @@ class SPART:
         (SPART.py:181-184, 192, 202, 216, 228).  The three dicts are hashed as they are on every call (engine.raw_digest: ~30 us
         with xxhash); the digest -> (engine, band centres, band ids) resolved by the validating slow path is remembered per
         object, so a loop of run() calls pays for the conversion and validation of the tables once per distinct content."""
-        key = (_engine.raw_digest(self.optipar, self.ETpar, self.sensorinfo), self.device)
+        dev = self.device
+        if dev is None:                                          # (the memo must follow the CURRENT device, like get_engine)
+            import torch
+            dev = torch.cuda.current_device() if torch.cuda.is_available() else None
+        key = (_engine.raw_digest(self.optipar, self.ETpar, self.sensorinfo), dev)
         memo = self.__dict__.setdefault("_engine_memo", {})
         hit = memo.get(key)
         if hit is None:
