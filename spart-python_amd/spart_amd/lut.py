@@ -135,6 +135,8 @@ def generate_lut(params, sensor, path=None, dtype="float32", chunk=1 << 18, devi
     nb = eng.nb
     npdt = np.float32 if dtype in ("float32", "fp32", "f32") else np.float64
     tdt = torch.float32 if npdt is np.float32 else torch.float64
+    if path is not None and out is not None:
+        raise ValueError("generate_lut: give `path` (results land in the directory's .npy files) or `out` (caller-owned arrays), not both")
     if path is not None:
         whole = open_lut_files(path, [(k, npdt, (Btot, nb)) for k in COLUMNS] + [("params", np.float64, tuple(P.shape))],
                                world, rank, group)
