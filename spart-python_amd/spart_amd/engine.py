@@ -440,7 +440,7 @@ class Engine:
 
     def run(self, params, dtype="float32", rho_thermal=None, tau_thermal=None, materialize=(), out=None,
             prune=False, rdry=None, f32_columns=False, f32_bands=False, lidf="literal", _workspace=None,
-            canopy_lidf=None, nlayers=None):
+            canopy_lidf=None, nlayers=None, _defer=False):
         """SPART(...).run() for every column of ``params`` (SPART.py:162-269).
 
         params : (27, B) float64 device tensor (rows = spart_amd.workloads.PARAM_NAMES) or a list of 27
@@ -537,18 +537,51 @@ class Engine:
                     res[name] = torch.empty((4, _lib.NWLS) if name == "band_mean" else (B, self.nb), dtype=td,
                                             device=self.device)
                 setattr(mat, name, res[name].data_ptr())
+        if _defer and _workspace is None:                  # a prepared call owns its scratch (other calls on the engine do not disturb it)
+            n = int(self.lib.spart_workspace_bytes(self.ctx, dt, B))
+            _workspace = torch.empty(max(n, 256), dtype=torch.uint8, device=self.device)
         if _workspace is not None:
             ws, wsn = ctypes.c_void_p(_workspace.data_ptr()), ctypes.c_size_t(_workspace.numel())
         else:
             ws, wsn = self._workspace(dt, B)
-        self.calls["spart_run_batch"] += 1
-        rc = self.lib.spart_run_batch(self.ctx, dt, B, col_ptrs if col_ptrs is not None else self._ptrs(cols),
-                                      th[0].data_ptr() if th[0] is not None else None,
-                                      th[1].data_ptr() if th[1] is not None else None, res["R_TOC"].data_ptr(),
-                                      res["R_TOA"].data_ptr(), res["L_TOA"].data_ptr(),
-                                      ctypes.byref(mat) if mat is not None else None, ws, wsn, self._stream())
-        _lib.check(self.lib, self.ctx, rc)
-        return res
+        args = (self.ctx, dt, B, col_ptrs if col_ptrs is not None else self._ptrs(cols),
+                th[0].data_ptr() if th[0] is not None else None, th[1].data_ptr() if th[1] is not None else None,
+                res["R_TOC"].data_ptr(), res["R_TOA"].data_ptr(), res["L_TOA"].data_ptr(),
+                ctypes.byref(mat) if mat is not None else None, ws, wsn)
+        if not _defer:
+            self.calls["spart_run_batch"] += 1
+            rc = self.lib.spart_run_batch(*args, self._stream())
+            _lib.check(self.lib, self.ctx, rc)
+            return res
+        keep = (params, cols, th, li, rd, mat, res, _workspace)        # everything the argument pointers point into
+        lib, ctx, calls, stream_of, device = self.lib, self.ctx, self.calls, self.torch.cuda.current_stream, self.device
+
+        def call():
+            calls["spart_run_batch"] += 1
+            rc = lib.spart_run_batch(*args, ctypes.c_void_p(stream_of(device).cuda_stream))
+            if rc:
+                _lib.check(lib, ctx, rc)
+            return keep[6]
+        return call
+
+    def prepare(self, params, dtype="float32", out=None, **kw):
+        """run() with its argument marshalling done ONCE: returns ``call()`` which issues the same spart_run_batch on the current
+        stream over the SAME resident buffers (``params`` a (27, B) float64 device tensor, ``out`` the preallocated results, any
+        thermal / lidf tensors), with nothing but the ctypes call on the hot path -- what a loop over small batches wants when
+        a HIP-graph capture is too rigid (the stream may change from call to call).  The call owns its workspace."""
+        torch = self.torch
+        if not (torch.is_tensor(params) and params.dim() == 2 and params.dtype == torch.float64 and params.is_contiguous()
+                and params.device == self.device):
+            raise ValueError("prepare() needs a contiguous (27, B) float64 tensor on the engine's device")
+        if out is None or any(k not in out for k in ("R_TOC", "R_TOA", "L_TOA")):
+            raise ValueError("prepare() needs preallocated out['R_TOC'|'R_TOA'|'L_TOA']")
+        if kw.get("rdry") is not None:
+            raise ValueError("prepare(): user dry-soil spectra are re-laid out per call (row pitch): use run()")
+        for k in ("rho_thermal", "tau_thermal", "canopy_lidf"):
+            v = kw.get(k)
+            if v is not None and not (torch.is_tensor(v) and v.device == self.device):
+                raise ValueError(f"prepare(): {k} must be a tensor on the engine's device (its storage is reused by every call)")
+        return self.run(params, dtype, out=out, _defer=True, **kw)
 
     def _check_out(self, name, t, shape, td):
         """a caller-supplied output must be exactly what the kernels write: they get its data_ptr() and nothing else"""

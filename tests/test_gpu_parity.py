@@ -766,6 +766,43 @@ def test_engine_capture_and_output_validation(torch_mod):
         eng.lut_nearest(out["R_TOA"], out["R_TOA"][:5], weights=np.ones(12))
 
 
+def test_prepared_call_is_the_same_call(torch_mod):
+    """Engine.prepare: run()'s argument marshalling done once; call() issues the same spart_run_batch over the same resident
+    buffers -- new inputs written into them are seen, any stream may issue it, results are bit-identical to run()."""
+    from spart_amd import get_engine, workloads
+    torch = torch_mod
+    eng = get_engine("Sentinel2A-MSI", 0)
+    B = 4099
+    Pa = torch.as_tensor(workloads.lhs_params(B, "full", seed=3).T.copy(), device="cuda:0")
+    Pb = torch.as_tensor(workloads.lhs_params(B, "full", seed=4).T.copy(), device="cuda:0")
+    lidf = torch.as_tensor(np.random.default_rng(1).dirichlet(np.full(13, 2.0), size=B), device="cuda:0")
+    P = Pa.clone()
+    out = {k: torch.empty((B, 13), dtype=torch.float64, device="cuda:0") for k in ("R_TOC", "R_TOA", "L_TOA", "La")}
+    n0 = eng.calls["spart_run_batch"]
+    call = eng.prepare(P, "float64", out=out, materialize=["La"], prune=True, canopy_lidf=lidf, nlayers=24)
+    assert eng.calls["spart_run_batch"] == n0                      # nothing issued yet
+    for src in (Pa, Pb, Pa):
+        P.copy_(src)
+        res = call()
+        ref = eng.run(src, "float64", materialize=["La"], prune=True, canopy_lidf=lidf, nlayers=24)
+        assert res["R_TOC"] is out["R_TOC"]
+        for k in out:
+            assert torch.equal(out[k], ref[k]), k
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        P.copy_(Pb)
+        call()
+    s.synchronize()
+    assert torch.equal(out["R_TOA"], eng.run(Pb, "float64", prune=True, canopy_lidf=lidf, nlayers=24)["R_TOA"])
+    with pytest.raises(ValueError):
+        eng.prepare(P.cpu(), "float64", out=out)
+    with pytest.raises(ValueError):
+        eng.prepare(P, "float64", out=out, rho_thermal=0.01)       # host values would be frozen at prepare time: refused
+    with pytest.raises(ValueError):
+        eng.prepare(P, "float64", out=out, rdry=torch.zeros((B, 2001), dtype=torch.float64, device="cuda:0"))
+
+
 def test_lut_generation_streams_chunks(tmp_path, torch_mod):
     """generate_lut: chunked, double-buffered H2D / kernels / D2H; ragged last chunk; on-disk layout round trip."""
     import spart_amd
